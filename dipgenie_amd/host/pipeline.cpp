@@ -1,0 +1,940 @@
+#include "pipeline.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <numeric>
+#include <queue>
+#include <stdexcept>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "seq_reader.hpp"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace dg {
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void Pipeline::stamp(const char *name, double t0) {
+    double dt = now_s() - t0;
+    sum.stage_s.emplace_back(name, dt);
+    if (!opt.quiet) fprintf(stderr, "[dg::stage] %-28s %.3f s\n", name, dt);
+}
+
+// ======================================================================================
+// Solver::read_gfa  (solver.cpp:27-227)
+// ======================================================================================
+void Pipeline::read_gfa_from(const GfaGraph &g) {
+    n_vtx = g.n_seg();
+    node_seq.assign(g.seg_seq.begin(), g.seg_seq.end());               // :37-43
+    adj_list.assign(n_vtx, {});
+    for (uint32_t s = 0; s < n_vtx; ++s)                               // :60-91 forward strand only
+        for (uint32_t w : g.arcs[(size_t)2 * s]) adj_list[s].push_back(w >> 1);
+
+    num_walks = (uint32_t)g.walks.size();                              // :98
+    paths.assign(num_walks, {});
+    hap_id2name.clear();
+    for (uint32_t w = 0; w < num_walks; ++w) {                         // :108-125
+        hap_id2name.push_back(g.walks[w].sample + "." + std::to_string(g.walks[w].hap));
+        for (uint32_t x : g.walks[w].v) {
+            if (x & 1) exit(1);                                        // :116-119 (silent, as the reference)
+            paths[w].push_back(x >> 1);
+        }
+    }
+
+    const int32_t V = (int32_t)n_vtx;
+    const int64_t INF = std::numeric_limits<int64_t>::max() / 4;       // :131
+    std::vector<int64_t> pos(V, INF);
+    for (size_t w = 0; w < paths.size(); ++w) {
+        const auto &pw = paths[w];
+        for (int64_t t = 0; t < (int64_t)pw.size(); ++t) {
+            int32_t vtx = (int32_t)pw[t];
+            if (vtx < 0 || vtx >= V) continue;
+            if (t < pos[vtx]) pos[vtx] = t;
+        }
+    }
+    {
+        int64_t max_seed = -1;                                         // :146-153
+        for (int32_t v = 0; v < V; ++v) if (pos[v] != INF) max_seed = std::max(max_seed, pos[v]);
+        int64_t fallback_start = (max_seed >= 0 ? max_seed + 1 : 0);
+        for (int32_t v = 0; v < V; ++v) if (pos[v] == INF) pos[v] = fallback_start;
+    }
+    bool changed = true;                                               // :158-171
+    int iter = 0, iter_cap = std::max(10, V);
+    while (changed && iter++ < iter_cap) {
+        changed = false;
+        for (size_t w = 0; w < paths.size(); ++w) {
+            const auto &pw = paths[w];
+            for (size_t t = 1; t < pw.size(); ++t) {
+                int32_t u = (int32_t)pw[t - 1], v = (int32_t)pw[t];
+                if (u < 0 || u >= V || v < 0 || v >= V) continue;
+                int64_t need = pos[u] + 1;
+                if (pos[v] < need) { pos[v] = need; changed = true; }
+            }
+        }
+    }
+    std::vector<std::pair<int64_t, int32_t>> by_pos;                   // :174-199
+    by_pos.reserve(V);
+    for (int32_t v = 0; v < V; ++v) by_pos.emplace_back(pos[v], v);
+    std::sort(by_pos.begin(), by_pos.end());
+    std::vector<int32_t> dense_pos(V, -1);
+    int32_t cur_rank = -1;
+    int64_t prev_col = std::numeric_limits<int64_t>::min();
+    for (auto &p : by_pos) {
+        if (p.first != prev_col) { ++cur_rank; prev_col = p.first; }
+        dense_pos[p.second] = cur_rank;
+    }
+    top_order_map.assign(V, -1);
+    for (int32_t i = 0; i < (int32_t)by_pos.size(); ++i) top_order_map[by_pos[i].second] = i;
+
+    for (int32_t u = 0; u < V; ++u) {                                  // :216-223
+        auto &nei = adj_list[u];
+        std::sort(nei.begin(), nei.end(), [&](uint32_t a, uint32_t b) {
+            int32_t ca = dense_pos[a], cb = dense_pos[b];
+            if (ca != cb) return ca < cb;
+            return a < b;
+        });
+    }
+}
+
+int Pipeline::load_graph(std::string &err) {
+    double t0 = now_s();
+    GfaGraph g;
+    if (!read_gfa_file(opt.gfa_file, g, err)) return -1;
+    read_gfa_from(g);
+    stamp("gfa_read+read_gfa", t0);
+    return 0;
+}
+
+int Pipeline::load_reads(std::string &err) {                           // solver.cpp:230-245
+    double t0 = now_s();
+    reads.clear();
+    if (!read_sequences(opt.reads_file, reads, err)) return -1;
+    stamp("read_ip_reads", t0);
+    return 0;
+}
+
+// ======================================================================================
+// Solver::compute_and_classify_anchors  (solver.cpp:449-887)
+// ======================================================================================
+int Pipeline::compute_and_classify_anchors(std::string &err) {
+    const int k = opt.k;
+    // ---- haplotype sketches (index_kmers, solver.cpp:277-363) ----
+    double t0 = now_s();
+    struct HapIndex { std::vector<uint64_t> hash; std::vector<uint32_t> voff; std::vector<int32_t> v; };
+    std::vector<HapIndex> kmer_index(num_walks);
+    sum.minimizers_per_hap.assign(num_walks, 0);
+    for (uint32_t h = 0; h < num_walks; ++h) {
+        std::string hap;                                               // :283-285
+        std::vector<int64_t> seg_start(paths[h].size() + 1, 0);
+        {
+            size_t tot = 0;
+            for (size_t i = 0; i < paths[h].size(); ++i) { seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
+            seg_start[paths[h].size()] = (int64_t)tot;
+            hap.reserve(tot);
+            for (size_t i = 0; i < paths[h].size(); ++i) hap += node_seq[paths[h][i]];
+        }
+        uint64_t *hh = nullptr; int64_t *pp = nullptr; int64_t n = 0;
+        int rc = be.sketch_haplotype(be.ctx, hap.data(), (int64_t)hap.size(), k, opt.w, &hh, &pp, &n);
+        if (rc != 0) { err = std::string("sketch_haplotype failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
+        HapIndex &ix = kmer_index[h];
+        ix.hash.assign(hh, hh + n);
+        ix.voff.reserve(n + 1);
+        ix.voff.push_back(0);
+        std::vector<int32_t> uniq;
+        size_t seg = 0;
+        for (int64_t m = 0; m < n; ++m) {                              // :343-357 position -> vertex span
+            int64_t p = pp[m];
+            // positions are non-decreasing; seg = index of the path step containing base p
+            if (seg_start[seg] > p) seg = 0;
+            while (seg + 1 < seg_start.size() - 1 && seg_start[seg + 1] <= p) ++seg;
+            uniq.clear();
+            size_t s2 = seg;
+            for (;;) {
+                int32_t vtx = (int32_t)paths[h][s2];
+                if (seg_start[s2 + 1] > seg_start[s2] &&               // empty segments contribute no base
+                    std::find(uniq.begin(), uniq.end(), vtx) == uniq.end()) uniq.push_back(vtx);
+                if (seg_start[s2 + 1] >= p + k) break;
+                ++s2;
+            }
+            std::sort(uniq.begin(), uniq.end(), [&](int32_t a, int32_t b) { return top_order_map[a] < top_order_map[b]; });
+            ix.v.insert(ix.v.end(), uniq.begin(), uniq.end());
+            ix.voff.push_back((uint32_t)ix.v.size());
+        }
+        be.free_buf(hh); be.free_buf(pp);
+        sum.minimizers_per_hap[h] = n;
+    }
+    if (!opt.quiet) {
+        std::cerr << "Number of Minimizers" << std::endl;              // :467-474
+        for (uint32_t h = 0; h < num_walks; ++h) fprintf(stderr, "%s : %d\n", hap_id2name[h].c_str(), (int)sum.minimizers_per_hap[h]);
+    }
+    stamp("index_kmers", t0);
+
+    // ---- read sketches: Read_hashes / Sp_R / kmer_count (solver.cpp:526-555, 711-732) ----
+    t0 = now_s();
+    std::vector<uint64_t> sp_hash;     // sorted distinct read-minimizer hashes; id = rank (:541-546)
+    std::vector<int32_t> sp_count;     // number of reads containing it (== kmer_count)
+    {
+        std::vector<int64_t> off(reads.size() + 1, 0);
+        for (size_t r = 0; r < reads.size(); ++r) off[r + 1] = off[r] + (int64_t)reads[r].second.size();
+        std::string bases;
+        bases.reserve((size_t)off.back());
+        for (auto &rd : reads) bases += rd.second;
+        uint64_t *hh = nullptr; int32_t *cc = nullptr; int64_t n = 0;
+        int rc = be.sketch_reads(be.ctx, bases.data(), off.data(), (int64_t)reads.size(), k, opt.w, &hh, &cc, &n);
+        if (rc != 0) { err = std::string("sketch_reads failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
+        sp_hash.assign(hh, hh + n);
+        sp_count.assign(cc, cc + n);
+        be.free_buf(hh); be.free_buf(cc);
+    }
+    count_sp_r = (int32_t)sp_hash.size();
+    sum.spectrum = count_sp_r;
+    if (!opt.quiet) fprintf(stderr, "[M::%s] Indexed reads with spectrum size: %d\n", __func__, count_sp_r);   // :558
+    stamp("compute_hashes+Sp_R", t0);
+
+    // ---- compute_anchors (solver.cpp:415-446, 560-575): hap minimizers whose hash is in Sp_R ----
+    t0 = now_s();
+    struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
+    std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
+    std::vector<std::vector<int32_t>> ids(num_walks);
+#pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
+    for (int32_t h = 0; h < (int32_t)num_walks; ++h) {
+        auto &ix = kmer_index[h];
+        ids[h].resize(ix.hash.size());
+        for (size_t m = 0; m < ix.hash.size(); ++m) {
+            auto it = std::lower_bound(sp_hash.begin(), sp_hash.end(), ix.hash[m]);
+            ids[h][m] = (it != sp_hash.end() && *it == ix.hash[m]) ? (int32_t)(it - sp_hash.begin()) : -1;
+        }
+    }
+    for (uint32_t h = 0; h < num_walks; ++h)
+        for (int32_t id : ids[h]) if (id >= 0) bucket_off[id + 1]++;
+    for (int32_t r = 0; r < count_sp_r; ++r) bucket_off[r + 1] += bucket_off[r];
+    std::vector<Raw> raw((size_t)bucket_off[count_sp_r]);
+    {
+        std::vector<int64_t> fill(bucket_off.begin(), bucket_off.end() - 1);
+        for (uint32_t h = 0; h < num_walks; ++h)       // (h asc, minimizer order asc) inside every id
+            for (size_t m = 0; m < ids[h].size(); ++m)
+                if (ids[h][m] >= 0) raw[fill[ids[h][m]]++] = Raw{(int32_t)h, (uint32_t)m};
+    }
+
+    // ---- shared-anchor filter (:590-633) + occurrence sort (:641-663) ----
+    occs.clear(); vpool.clear();
+    const float thr = opt.threshold * num_walks;                       // float * uint32 -> float (:618)
+    std::vector<std::string> keys;
+    std::vector<int32_t> order, grp;
+    for (int32_t r = 0; r < count_sp_r; ++r) {
+        const int64_t b = bucket_off[r], e = bucket_off[r + 1];
+        if (b == e) continue;
+        const int32_t n = (int32_t)(e - b);
+        keys.resize(n);
+        for (int32_t t = 0; t < n; ++t) {                              // :600-603 "v0_v1_..._"
+            const Raw &o = raw[b + t];
+            const auto &ix = kmer_index[o.h];
+            std::string &s = keys[t];
+            s.clear();
+            for (uint32_t q = ix.voff[o.m]; q < ix.voff[o.m + 1]; ++q) { s += std::to_string(ix.v[q]); s += '_'; }
+        }
+        order.resize(n);
+        std::iota(order.begin(), order.end(), 0);
+        // std::map<std::string,...> iteration = lexicographic on the key; inside a key, push order
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return keys[x] < keys[y]; });
+        bool all_haps = false;                                         // :615-622
+        for (int32_t i = 0; i < n;) {
+            int32_t j = i + 1;
+            while (j < n && keys[order[j]] == keys[order[i]]) ++j;
+            if ((float)(j - i) >= thr) { all_haps = true; break; }
+            i = j;
+        }
+        if (all_haps) continue;                                        // :624-632 id dropped entirely
+        // Anchor_hits_1[r][h] in map-iteration order, then std::sort per (r,h) (:641-663)
+        for (uint32_t h = 0; h < num_walks; ++h) {
+            grp.clear();
+            for (int32_t i = 0; i < n; ++i) if (raw[b + order[i]].h == (int32_t)h) grp.push_back(order[i]);
+            if (grp.empty()) continue;
+            const auto &ix = kmer_index[h];
+            std::sort(grp.begin(), grp.end(), [&](int32_t x, int32_t y) {
+                const uint32_t mx = raw[b + x].m, my = raw[b + y].m;
+                const int32_t ax0 = ix.v[ix.voff[mx]], ay0 = ix.v[ix.voff[my]];
+                if (ax0 != ay0) return ax0 < ay0;
+                return ix.v[ix.voff[mx + 1] - 1] < ix.v[ix.voff[my + 1] - 1];
+            });
+            for (int32_t x : grp) {
+                const uint32_t m = raw[b + x].m;
+                Occ o{r, (int32_t)h, (uint32_t)vpool.size(), ix.voff[m + 1] - ix.voff[m]};
+                vpool.insert(vpool.end(), ix.v.begin() + ix.voff[m], ix.v.begin() + ix.voff[m + 1]);
+                occs.push_back(o);
+            }
+        }
+    }
+    sum.anchors_per_hap.assign(num_walks, 0);
+    for (auto &o : occs) sum.anchors_per_hap[o.h]++;
+    if (!opt.quiet) {
+        std::cerr << "Number of Anchors" << std::endl;                 // :674-685
+        for (uint32_t h = 0; h < num_walks; ++h) fprintf(stderr, "%s : %d\n", hap_id2name[h].c_str(), (int)sum.anchors_per_hap[h]);
+    }
+    stamp("compute_anchors+filter+sort", t0);
+
+    // ---- multiplicity histogram, fit, classify (:745-879) ----
+    t0 = now_s();
+    std::map<int32_t, int32_t> kmer_freq;                              // :745-750
+    for (int32_t c : sp_count) kmer_freq[c] += 1;
+    std::vector<HistBin> hist;
+    int max_mult = 0;
+    for (auto &kv : kmer_freq) { hist.push_back({(int)kv.first, (double)kv.second}); max_mult = std::max(max_mult, (int)kv.first); }
+    if (!opt.quiet) std::cout << "Classifying kmers..." << std::endl;  // :784
+    sum.fit = kg_fit(hist, /*max_copy=*/10, max_mult, opt.threads);
+    const KGParams &P = sum.fit.P;
+    if (!opt.quiet)
+        fprintf(stderr, "[M::%s] Fitted model: best NLL=%.2f, u_v=%.2f (hom mean), sd_v=%.2f (hom SD), "
+                "var_w=%.2f, p_d=%.2f, zp_copy=%.2f, zp_copy_het=%.2f, err_shape=%.2f, max_copy=%d\n",
+                __func__, sum.fit.nll, P.u_v, P.sd_v, P.var_w, P.p_d, P.zp_copy, P.zp_copy_het, P.err_shape, P.max_copy);
+    std::vector<int8_t> label(max_mult + 1, -1);
+    homo_bv.assign(count_sp_r, 0);                                     // :830-879
+    int64_t n_hom = 0;
+    for (int32_t id = 0; id < count_sp_r; ++id) {
+        int m = sp_count[id];
+        if (m == 0) continue;
+        if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
+        homo_bv[id] = (uint8_t)label[m];
+        n_hom += label[m];
+    }
+    if (!opt.quiet) {
+        int64_t tot = std::max<int64_t>(1, count_sp_r);
+        fprintf(stderr, "[M::%s] Phasing done. Homozygous: %.2f%%, Heterozygous: %.2f%%, Total kmers: %lld\n", __func__,
+                100.f * float(n_hom) / tot, 100.f * float(count_sp_r - n_hom) / tot, (long long)count_sp_r);
+    }
+    stamp("fit+classify", t0);
+    return 0;
+}
+
+// ======================================================================================
+// ExpandedGraph  (ExpandedGraph.hpp:29-102, 269-409)
+// ======================================================================================
+void ExpandedGraph::topologically_reorder(int sink) {
+    const std::size_t n = adj_list.size();
+    std::vector<int> indeg(n, 0);
+    for (auto &nbrs : adj_list) for (auto &vw : nbrs) ++indeg[vw.first];
+    std::queue<int> q;
+    for (std::size_t v = 0; v < n; ++v) if (indeg[v] == 0 && (int)v != sink) q.push((int)v);
+    bool sink_ready = (indeg[sink] == 0);
+    std::vector<int> order;
+    order.reserve(n);
+    while (!q.empty() || sink_ready) {
+        int u;
+        if (!q.empty()) { u = q.front(); q.pop(); }
+        else { u = sink; sink_ready = false; }
+        order.push_back(u);
+        for (auto &vw : adj_list[u])
+            if (--indeg[vw.first] == 0) { if (vw.first == sink) sink_ready = true; else q.push(vw.first); }
+    }
+    if (order.size() != n) throw std::runtime_error("Graph contains a cycle; topological order impossible");
+    std::vector<int> new_idx(n);
+    for (std::size_t i = 0; i < n; ++i) new_idx[order[i]] = (int)i;
+    std::vector<std::vector<int>> new_color(n), new_orig(n);
+    std::vector<int> new_hap(n);
+    for (std::size_t i = 0; i < n; ++i) {
+        new_color[i] = std::move(color[order[i]]);
+        new_orig[i] = std::move(original_vertex[order[i]]);
+        new_hap[i] = haplotype[order[i]];
+    }
+    color.swap(new_color); original_vertex.swap(new_orig); haplotype.swap(new_hap);
+    std::vector<std::vector<std::pair<int, int>>> new_adj(n);
+    for (std::size_t old_u = 0; old_u < n; ++old_u) {
+        int u = new_idx[old_u];
+        new_adj[u].reserve(adj_list[old_u].size());
+        for (auto &vw : adj_list[old_u]) new_adj[u].emplace_back(new_idx[vw.first], vw.second);
+    }
+    adj_list.swap(new_adj);
+}
+
+int ExpandedGraph::strict_bfs_levelize_and_reorder() {
+    const std::size_t n = adj_list.size();
+    std::vector<int> indeg(n, 0), outdeg(n, 0);
+    for (std::size_t u = 0; u < n; ++u) {
+        outdeg[u] = (int)adj_list[u].size();
+        for (const auto &vw : adj_list[u]) ++indeg[vw.first];
+    }
+    int source = -1;
+    for (std::size_t v = 0; v < n; ++v)
+        if (indeg[v] == 0 && outdeg[v] > 0) {
+            if (source == -1) source = (int)v;
+            else { std::cout << "Uh oh, multiple potential sources found while leveling\n"; std::exit(-1); }
+        }
+    const int n0 = (int)adj_list.size();
+    if (n0 == 0) return 0;
+    if (source < 0 || source >= n0) throw std::runtime_error("bad source index");
+
+    std::vector<int> dist(n0, -1);                                     // 1) BFS
+    {
+        std::queue<int> q;
+        dist[source] = 0; q.push(source);
+        while (!q.empty()) {
+            int u = q.front(); q.pop();
+            for (auto &vw : adj_list[u]) if (dist[vw.first] == -1) { dist[vw.first] = dist[u] + 1; q.push(vw.first); }
+        }
+    }
+    std::vector<int> topo;                                             // 2) Kahn over ALL indeg-0 vertices
+    topo.reserve(n0);
+    {
+        std::queue<int> qk;
+        for (int v = 0; v < n0; ++v) if (indeg[v] == 0) qk.push(v);
+        while (!qk.empty()) {
+            int u = qk.front(); qk.pop();
+            topo.push_back(u);
+            for (auto &vw : adj_list[u]) if (--indeg[vw.first] == 0) qk.push(vw.first);
+        }
+    }
+    if ((int)topo.size() != n0) throw std::runtime_error("Graph contains a cycle; strict leveling requires a DAG");
+    std::vector<int> lvl(n0, 0);                                       // 3) seed / relax
+    for (int v = 0; v < n0; ++v) if (dist[v] >= 0) lvl[v] = dist[v];
+    for (int u : topo) for (auto &vw : adj_list[u]) if (lvl[vw.first] <= lvl[u]) lvl[vw.first] = lvl[u] + 1;
+
+    // 4) dummies for skipped levels
+    std::vector<std::vector<std::pair<int, int>>> next_adj(n0);
+    std::vector<std::vector<int>> next_color = std::move(color);
+    std::vector<std::vector<int>> next_orig = std::move(original_vertex);
+    std::vector<int> next_lvl = lvl;
+    std::vector<int> next_hap = haplotype;
+    for (int u = 0; u < n0; ++u) {
+        for (auto &vw : adj_list[u]) {
+            const int v = vw.first, w = vw.second;
+            int gap = next_lvl[v] - next_lvl[u] - 1;
+            if (gap <= 0) {
+                next_adj[u].emplace_back(v, w);
+            } else {
+                int prev = u;
+                for (int step = 1; step <= gap; ++step) {
+                    int dummy = (int)next_adj.size();                  // add_dummy (:326-334)
+                    next_adj.emplace_back();
+                    next_color.emplace_back();
+                    next_orig.emplace_back(next_orig[u]);
+                    next_lvl.push_back(next_lvl[u] + step);
+                    next_hap.push_back(haplotype[u]);
+                    next_adj[prev].emplace_back(dummy, (step == 1 ? w : 0));
+                    prev = dummy;
+                }
+                next_adj[prev].emplace_back(v, 0);
+            }
+        }
+    }
+    adj_list.swap(next_adj);
+    color.swap(next_color);
+    original_vertex.swap(next_orig);
+    level.swap(next_lvl);
+    haplotype.swap(next_hap);
+
+    // 5) order by (level, id)
+    const int n1 = (int)adj_list.size();
+    int max_level = 0;
+    for (int v = 0; v < n1; ++v) if (level[v] > max_level) max_level = level[v];
+    std::vector<int> width(max_level + 1, 0);
+    for (int v = 0; v < n1; ++v) ++width[level[v]];
+    int max_width = 0;
+    for (int w : width) if (w > max_width) max_width = w;
+    // stable sort by (level, id) over ids 0..n1-1 == counting sort by level
+    std::vector<int> start(max_level + 2, 0);
+    for (int l = 0; l <= max_level; ++l) start[l + 1] = start[l] + width[l];
+    std::vector<int> order(n1), new_id(n1, -1);
+    {
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int v = 0; v < n1; ++v) order[fill[level[v]]++] = v;
+    }
+    for (int i = 0; i < n1; ++i) new_id[order[i]] = i;
+    std::vector<std::vector<int>> new_color(n1), new_orig(n1);
+    std::vector<int> new_level(n1), new_hap(n1);
+    for (int i = 0; i < n1; ++i) {
+        int old = order[i];
+        new_color[i] = std::move(color[old]);
+        new_orig[i] = std::move(original_vertex[old]);
+        new_level[i] = level[old];
+        new_hap[i] = haplotype[old];
+    }
+    color.swap(new_color); original_vertex.swap(new_orig); level.swap(new_level); haplotype.swap(new_hap);
+    std::vector<std::vector<std::pair<int, int>>> new_adj(n1);
+    for (int old_u = 0; old_u < n1; ++old_u) {
+        int u = new_id[old_u];
+        new_adj[u].reserve(adj_list[old_u].size());
+        for (auto &vw : adj_list[old_u]) new_adj[u].emplace_back(new_id[vw.first], vw.second);
+    }
+    adj_list.swap(new_adj);
+    vertices_in_level.clear();
+    vertices_in_level.resize(max_level + 1);
+    for (int u = 0; u < n1; ++u) vertices_in_level[level[u]].push_back(u);
+    return max_width;
+}
+
+// ======================================================================================
+// DpGraphStorage
+// ======================================================================================
+dg_dp_graph DpGraphStorage::view(int R) const {
+    dg_dp_graph g;
+    g.n_vertices = (int32_t)(out_off.size() - 1);
+    g.n_levels = (int32_t)(level_off.size() - 1);
+    g.R = R;
+    g.level_off = level_off.data();
+    g.out_off = out_off.data(); g.out_dst = out_dst.data(); g.out_w = out_w.data();
+    g.hom_off = hom_off.data(); g.het_off = het_off.data();
+    g.hom_col = hom_col.data(); g.het_col = het_col.data();
+    return g;
+}
+
+namespace {
+template <class T> void wr(std::ofstream &f, const std::vector<T> &v) {
+    uint64_t n = v.size();
+    f.write((const char *)&n, 8);
+    f.write((const char *)v.data(), (std::streamsize)(n * sizeof(T)));
+}
+template <class T> bool rd(std::ifstream &f, std::vector<T> &v) {
+    uint64_t n = 0;
+    if (!f.read((char *)&n, 8)) return false;
+    v.resize(n);
+    return (bool)f.read((char *)v.data(), (std::streamsize)(n * sizeof(T)));
+}
+}  // namespace
+
+// file = "DGDP0001" | int32 R | 8 length-prefixed arrays (level_off,out_off,out_dst,out_w,hom_off,hom_col,het_off,het_col)
+bool DpGraphStorage::save(const std::string &path, int R) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.write("DGDP0001", 8);
+    int32_t r = R;
+    f.write((const char *)&r, 4);
+    wr(f, level_off); wr(f, out_off); wr(f, out_dst); wr(f, out_w);
+    wr(f, hom_off); wr(f, hom_col); wr(f, het_off); wr(f, het_col);
+    return (bool)f;
+}
+bool DpGraphStorage::load(const std::string &path, int &R) {
+    std::ifstream f(path, std::ios::binary);
+    char magic[8];
+    if (!f || !f.read(magic, 8) || memcmp(magic, "DGDP0001", 8) != 0) return false;
+    int32_t r;
+    if (!f.read((char *)&r, 4)) return false;
+    R = r;
+    return rd(f, level_off) && rd(f, out_off) && rd(f, out_dst) && rd(f, out_w) &&
+           rd(f, hom_off) && rd(f, hom_col) && rd(f, het_off) && rd(f, het_col);
+}
+
+// ======================================================================================
+// haploid DP  (approximator.cpp:44-168) -- CPU by design
+// ======================================================================================
+std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
+    int n = (int)g.adj_list.size();
+    const std::size_t N = (std::size_t)n * (R + 1);
+    std::vector<int> dp(N, 0), back_vtx(N, -1), back_r(N, -1);         // :50-52 (0, not -inf: quirk kept)
+    auto idx = [&](int v, int r) -> std::size_t { return std::size_t(v) * (R + 1) + r; };
+    for (int u = 0; u < n; u++)
+        for (int r = 0; r <= R; r++)
+            for (auto &vw : g.adj_list[u]) {
+                const int v = vw.first, w_uv = vw.second;
+                // NB the reference compares in size_t (int + size_t > int): :60
+                if (r + w_uv <= R && (std::size_t)dp[idx(u, r)] + g.color[v].size() > (std::size_t)dp[idx(v, r + w_uv)]) {
+                    dp[idx(v, r + w_uv)] = dp[idx(u, r)] + (int)g.color[v].size();
+                    back_vtx[idx(v, r + w_uv)] = u;
+                    back_r[idx(v, r + w_uv)] = r;
+                }
+            }
+    std::vector<int> colors_by_r;
+    std::vector<std::map<int, int>> occ_count_by_r;
+    for (int r = 0; r <= R; r++) {                                     // :74-102
+        std::unordered_set<int> true_colours;
+        std::map<int, int> occ_count;
+        int cur_vtx = n - 1, cur_r = r;
+        while (cur_vtx != -1) {
+            for (auto c : g.color[cur_vtx]) { true_colours.insert(c); occ_count[c] += 1; }
+            int temp_vtx = cur_vtx;
+            cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
+            cur_r = back_r[idx(temp_vtx, cur_r)];
+        }
+        colors_by_r.push_back((int)true_colours.size());
+        occ_count_by_r.push_back(occ_count);
+    }
+    if (!opt.quiet)
+        for (size_t i = 0; i + 1 < occ_count_by_r.size(); ++i) {       // :104-113
+            float avg = 0;
+            for (const auto &c : occ_count_by_r[i]) avg += c.second;
+            avg = avg / occ_count_by_r[i].size();
+            std::cout << "Approximation ratio certificate: " << avg << std::endl;
+        }
+    int best_r = 0;                                                    // :116-136
+    double max_delta = 0;
+    for (size_t i = 0; i + 1 < colors_by_r.size(); ++i) {
+        if (!opt.quiet) std::cout << "r: " << i << " true score: " << colors_by_r[i] << std::endl;
+        int delta = colors_by_r[i + 1] - colors_by_r[i];
+        if (std::abs(delta) > max_delta) max_delta = std::abs(delta);
+    }
+    for (size_t r = 0; r + 1 < colors_by_r.size(); ++r) {
+        int delta = colors_by_r[r + 1] - colors_by_r[r];
+        double angle_rad = std::atan(static_cast<double>(delta) / max_delta);
+        double angle_deg = angle_rad * 180.0 / M_PI;
+        if (!opt.quiet)
+            std::cout << "r: " << r << " -> " << r + 1 << ", \xCE\x94" "colors: " << delta << ", angle: " << angle_deg << "\xC2\xB0" << std::endl;
+        if (angle_deg < 5 /*HAP_ANGLE_THRESHOLD*/) { best_r = (int)r; break; }
+    }
+    if (!opt.quiet) std::cerr << "Recombination count: " << best_r << std::endl;
+    sum.best_r_haploid = best_r;
+    std::vector<int> path;                                             // :141-153
+    int cur_vtx = n - 1, cur_r = best_r;
+    while (cur_vtx != -1) {
+        path.push_back(cur_vtx);
+        int temp_vtx = cur_vtx;
+        cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
+        cur_r = back_r[idx(temp_vtx, cur_r)];
+    }
+    std::reverse(path.begin(), path.end());
+    std::vector<int> out;
+    std::unordered_set<int> seen;                                      // remove_duplicates (:30-40)
+    for (auto u : path)
+        for (auto uo : g.original_vertex[u])
+            if (seen.insert(uo).second) out.push_back(uo);
+    return out;
+}
+
+// ======================================================================================
+// Approximator::solve  (approximator.cpp:1014-1331)
+// ======================================================================================
+int Pipeline::solve(std::string &err) {
+    double t0 = now_s();
+    int32_t number_of_vertices = 0;
+    for (size_t h = 0; h < paths.size(); h++) number_of_vertices += (int32_t)paths[h].size();
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> adj(2 + number_of_vertices);
+    std::vector<std::vector<int32_t>> v2e(n_vtx, std::vector<int32_t>(paths.size(), -1));
+    std::vector<std::vector<int32_t>> e2o(2 + number_of_vertices);
+    std::vector<int32_t> e2h(2 + number_of_vertices);
+
+    const int sink = (int)adj.size() - 1;
+    int32_t current_vertex = 1;
+    for (size_t h = 0; h < paths.size(); h++) {                        // :1029-1049
+        adj[0].push_back({current_vertex, 0});
+        for (size_t i = 0; i < paths[h].size(); i++) {
+            v2e[paths[h][i]][h] = current_vertex;
+            e2o[current_vertex].push_back((int32_t)paths[h][i]);
+            e2h[current_vertex] = (int32_t)h;
+            if (i < paths[h].size() - 1) adj[current_vertex].push_back({current_vertex + 1, 0});
+            else adj[current_vertex].push_back({(int32_t)sink, 0});
+            current_vertex++;
+        }
+    }
+    // recombination edges (:1051-1095)
+    std::vector<std::vector<int>> vertex_w_uv(n_vtx);
+    for (size_t u = 0; u < adj_list.size(); u++) vertex_w_uv[u] = std::vector<int>(adj_list[u].size(), -1);
+    current_vertex = (int32_t)adj.size();
+    for (size_t h = 0; h < paths.size(); h++) {
+        for (size_t i = 0; i < paths[h].size(); i++) {
+            int u = (int)paths[h][i];
+            for (size_t j = 0; j < adj_list[u].size(); j++) {
+                int v = (int)adj_list[u][j];
+                if (i == paths[h].size() - 1 || v != (int)paths[h][i + 1]) {
+                    if (vertex_w_uv[u][j] == -1) {
+                        adj.emplace_back();
+                        e2o.emplace_back();
+                        e2h.push_back(-1);
+                        vertex_w_uv[u][j] = current_vertex;
+                        current_vertex++;
+                    }
+                    adj[v2e[u][h]].push_back({vertex_w_uv[u][j], 1});
+                    if (adj[vertex_w_uv[u][j]].empty())
+                        for (auto v_e : v2e[v]) if (v_e >= 0) adj[vertex_w_uv[u][j]].push_back({v_e, 0});
+                }
+            }
+        }
+    }
+
+    // anchors -> AnchorRec per haplotype (:1114-1176)
+    std::vector<std::vector<int32_t>> color(adj.size());
+    std::vector<std::vector<AnchorRec>> anchorsByHap(paths.size());
+    std::vector<int32_t> color_to_anchor;
+    int nextID = (int)adj.size();
+    int colourID = 0;
+    {
+        size_t p = 0;
+        while (p < occs.size()) {                                      // ids without occurrences use no colour
+            const int32_t a = occs[p].a;
+            for (; p < occs.size() && occs[p].a == a; ++p) {           // occs sorted by (a, h, occurrence order)
+                const Occ &o = occs[p];
+                const int h = o.h;
+                int startOrig = vpool[o.off], endOrig = vpool[o.off + o.len - 1];
+                int startExp = v2e[startOrig][h], endExp = v2e[endOrig][h];
+                int nodeID;
+                if (startExp == endExp) {
+                    nodeID = startExp;
+                } else {
+                    adj[startExp].push_back({nextID, 0});
+                    adj.push_back({{endExp, 0}});
+                    e2o.emplace_back(vpool.begin() + o.off, vpool.begin() + o.off + o.len);
+                    color.push_back({});
+                    e2h.push_back(-1);
+                    nodeID = nextID++;
+                }
+                anchorsByHap[h].push_back({startOrig, endOrig, startExp, endExp, {colourID}, nodeID});
+            }
+            color_to_anchor.push_back(a);
+            colourID++;
+        }
+    }
+    const int n_colours = colourID;
+    sum.n_colours = n_colours;
+
+    // per-haplotype sweep: overlap edges + containment colour propagation (:1193-1246)
+    for (size_t h = 0; h < paths.size(); ++h) {
+        auto &vec = anchorsByHap[h];
+        if (vec.empty()) continue;
+        std::sort(vec.begin(), vec.end(), [](const AnchorRec &a, const AnchorRec &b) {
+            if (a.startExp != b.startExp) return a.startExp < b.startExp;
+            else return a.endExp < b.endExp;
+        });
+        std::vector<AnchorRec *> stk;
+        for (auto &anc : vec) {
+            while (!stk.empty() && stk.back()->endExp < anc.startExp) stk.pop_back();
+            if (!stk.empty() && anc.startExp <= stk.back()->endExp && stk.back()->nodeID != anc.nodeID)
+                adj[stk.back()->nodeID].push_back({anc.nodeID, 0});
+            for (int i = (int)stk.size() - 1; i >= 0; --i) {
+                if (anc.endExp <= stk[i]->endExp) {
+                    for (int c : anc.colours)
+                        if (std::find(stk[i]->colours.begin(), stk[i]->colours.end(), c) == stk[i]->colours.end())
+                            stk[i]->colours.push_back(c);
+                } else break;
+            }
+            stk.push_back(&anc);
+        }
+        for (const auto &anc : vec) {
+            auto &dst = color[anc.nodeID];
+            dst.insert(dst.end(), anc.colours.begin(), anc.colours.end());
+            std::sort(dst.begin(), dst.end());
+            dst.erase(std::unique(dst.begin(), dst.end()), dst.end());
+        }
+    }
+    { std::vector<std::vector<int32_t>>().swap(v2e); }
+
+    ExpandedGraph g;                                                   // :1249-1256
+    g.adj_list.resize(adj.size());
+    for (size_t u = 0; u < adj.size(); ++u) { g.adj_list[u].assign(adj[u].begin(), adj[u].end()); }
+    { std::vector<std::vector<std::pair<int32_t, int32_t>>>().swap(adj); }
+    g.color.resize(color.size());
+    for (size_t u = 0; u < color.size(); ++u) g.color[u].assign(color[u].begin(), color[u].end());
+    g.original_vertex.resize(e2o.size());
+    for (size_t u = 0; u < e2o.size(); ++u) g.original_vertex[u].assign(e2o[u].begin(), e2o[u].end());
+    g.haplotype.assign(e2h.begin(), e2h.end());
+    stamp("expanded_graph_build", t0);
+    t0 = now_s();
+    g.topologically_reorder(sink);
+    stamp("topologically_reorder", t0);
+
+    if (opt.ploidy == 1) {                                             // :1260-1278
+        t0 = now_s();
+        std::vector<int> dp_path = haploid_dp(g, opt.R);
+        std::string out;
+        for (auto u : dp_path) out += node_seq[u];
+        std::ofstream f(opt.hap_file, std::ios::out);
+        f << ">" << "dp_sol" << " LN:" << out.size() << std::endl;
+        for (size_t i = 0; i < out.size(); i += 80) f << out.substr(i, 80) << std::endl;
+        f.close();
+        sum.len1 = (int64_t)out.size();
+        stamp("haploid_dp+write", t0);
+    } else {
+        std::vector<uint8_t> color_homo_bv(n_colours, 0);              // :1283-1290
+        for (int c = 0; c < n_colours; ++c) if (homo_bv[color_to_anchor[c]]) color_homo_bv[c] = 1;
+        t0 = now_s();
+        g.strict_bfs_levelize_and_reorder();                           // :1302
+        stamp("strict_levelize", t0);
+        int rc = diploid(g, color_homo_bv, anchorsByHap, err);
+        if (rc != 0) return rc;
+    }
+    if (!opt.quiet) std::cout << "Diploid sequences written to: " << opt.hap_file << std::endl;   // :1330
+    return 0;
+}
+
+// ======================================================================================
+// diploid_dp_approximation_solver minus the level loop  (approximator.cpp:362-453, 720-1011)
+// ======================================================================================
+int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
+                      const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err) {
+    double t0 = now_s();
+    const int L = (int)g.vertices_in_level.size();
+    const int nV = (int)g.adj_list.size();
+    if (!opt.quiet && g.vertices_in_level[0].size() > 1) std::cout << "There is more than one source on level zero!" << std::endl;
+    // flatten (vertex ids are level-sorted: ExpandedGraph.hpp:360-407)
+    dpg = DpGraphStorage();
+    dpg.level_off.resize(L + 1);
+    dpg.level_off[0] = 0;
+    for (int l = 0; l < L; ++l) dpg.level_off[l + 1] = dpg.level_off[l] + (int32_t)g.vertices_in_level[l].size();
+    dpg.out_off.assign(nV + 1, 0);
+    for (int v = 0; v < nV; ++v) dpg.out_off[v + 1] = dpg.out_off[v] + (int64_t)g.adj_list[v].size();
+    dpg.out_dst.resize(dpg.out_off[nV]);
+    dpg.out_w.resize(dpg.out_off[nV]);
+    for (int v = 0; v < nV; ++v) {
+        int64_t o = dpg.out_off[v];
+        for (auto &vw : g.adj_list[v]) { dpg.out_dst[o] = vw.first; dpg.out_w[o] = (uint8_t)vw.second; ++o; }
+    }
+    dpg.hom_off.assign(nV + 1, 0);
+    dpg.het_off.assign(nV + 1, 0);
+    if (!opt.quiet) std::cout << "Creating hetro/hom-zygous colors per vertex lists" << std::endl;
+    for (int v = 0; v < nV; ++v) {                                     // :431-453 (colour lists are already sorted-unique)
+        std::vector<int> H, T;
+        for (int c : g.color[v]) { if (color_homo_bv.at(c) == 1) H.push_back(c); else T.push_back(c); }
+        std::sort(H.begin(), H.end()); H.erase(std::unique(H.begin(), H.end()), H.end());
+        std::sort(T.begin(), T.end()); T.erase(std::unique(T.begin(), T.end()), T.end());
+        dpg.hom_col.insert(dpg.hom_col.end(), H.begin(), H.end());
+        dpg.het_col.insert(dpg.het_col.end(), T.begin(), T.end());
+        dpg.hom_off[v + 1] = (int64_t)dpg.hom_col.size();
+        dpg.het_off[v + 1] = (int64_t)dpg.het_col.size();
+    }
+    sum.n_levels = L;
+    sum.n_vertices = nV;
+    stamp("dp_prologue_flatten", t0);
+    if (!opt.dump_prefix.empty()) dpg.save(opt.dump_prefix + ".dpg", opt.R);
+
+    // ---- the level loop + sink read-out: DEVICE (approximator.cpp:532-716, 774-785) ----
+    t0 = now_s();
+    if (!opt.quiet) std::cout << "Running DP" << std::endl;
+    const int R = opt.R;
+    const int cap = R + 8;
+    std::vector<int32_t> p1f(cap), p1t(cap), p2f(cap), p2t(cap);
+    dg_dp_graph view = dpg.view(R);
+    dg_dp_result res;
+    memset(&res, 0, sizeof(res));
+    res.p1_from = p1f.data(); res.p1_to = p1t.data(); res.p2_from = p2f.data(); res.p2_to = p2t.data();
+    res.cap = cap;
+    int rc = be.dp_solve_diploid(be.ctx, &view, &res);
+    if (rc != 0) { err = std::string("dp_solve_diploid failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
+    stamp("dp_level_loop", t0);
+    t0 = now_s();
+    sum.dp_value = res.value; sum.s_het = res.s_het; sum.cells = res.cells; sum.relaxations = res.relaxations;
+    if (!opt.quiet) std::cout << "DP value: " << res.value << std::endl;       // :776
+    std::vector<std::pair<int, int>> wp1, wp2;
+    for (int i = 0; i < res.n_p1 && i < cap; ++i) wp1.emplace_back(p1f[i], p1t[i]);
+    for (int i = 0; i < res.n_p2 && i < cap; ++i) wp2.emplace_back(p2f[i], p2t[i]);
+    const int r1 = (int)wp1.size() - 1, r2 = (int)wp2.size() - 1;              // :784-785
+
+    auto find_next_zero_hap = [&](int src, int target_hap) -> int {          // :732-755
+        if (g.haplotype.at(src) == target_hap && g.original_vertex.at(src).size() > 0) return src;
+        std::queue<int> q;
+        std::unordered_set<int> visited;
+        q.push(src); visited.insert(src);
+        while (!q.empty()) {
+            int u = q.front(); q.pop();
+            for (const auto &vw : g.adj_list[u]) {
+                if (vw.second != 0) continue;
+                if (!visited.insert(vw.first).second) continue;
+                if (g.haplotype.at(vw.first) == target_hap && g.original_vertex.at(vw.first).size() > 0) return vw.first;
+                q.push(vw.first);
+            }
+        }
+        return -1;
+    };
+
+    std::unordered_map<int, int> p_color_freq[2];
+    std::vector<int> p_colors[2];
+    std::string hap_seq[2];
+    for (int which = 0; which < 2; ++which) {                                 // :790-923
+        const auto &wedges = which == 0 ? wp1 : wp2;
+        const char *tag = which == 0 ? "P1" : "P2";
+        std::string &hs = hap_seq[which];
+        int start_exp = g.vertices_in_level.at(0).at(0);
+        for (int i = 0; i < (int)wedges.size(); i++) {
+            const auto &edge = wedges.at(i);
+            if (g.original_vertex[edge.first].size() != 1) {
+                std::cout << tag << ": Vertex " << edge.first << " in map back has " << g.original_vertex[edge.first].size()
+                          << " original vertices" << std::endl;
+                exit(1);
+            }
+            int end_exp = edge.first;
+            int h = g.haplotype.at(end_exp);
+            if (start_exp == g.vertices_in_level.at(0).at(0))
+                for (auto &v : g.vertices_in_level.at(1)) if (g.haplotype.at(v) == h) start_exp = v;
+            int start_org = g.original_vertex.at(start_exp).at(0);
+            int end_org = g.original_vertex.at(end_exp).at(0);
+            bool activated = false;
+            for (int t = 0; t < (int)paths[h].size(); t++) {
+                if ((int)paths[h][t] == start_org) activated = true;
+                if (activated) hs += node_seq[paths[h][t]];
+                if ((int)paths[h][t] == end_org) { activated = false; break; }
+            }
+            for (const auto &a : anchorsByHap[h])
+                if (a.startOrg > start_org && a.endOrg < end_org)
+                    for (auto c : a.colours) {
+                        if (p_color_freq[which].find(c) == p_color_freq[which].end()) { p_color_freq[which][c] = 1; p_colors[which].push_back(c); }
+                        else p_color_freq[which][c] += 1;
+                    }
+            if (g.level.at(edge.second) == L - 1) break;
+            const auto &next_edge = wedges.at(i + 1);
+            int next_hap = g.haplotype.at(next_edge.first);
+            int next_start = find_next_zero_hap(edge.second, next_hap);
+            if (next_start != -1) start_exp = next_start;
+            else std::cout << tag << " (path recovery) Could not find next_hap=" << next_hap << " from " << edge.second << " via 0-weight edges\n";
+        }
+    }
+    sum.r1 = r1; sum.r2 = r2;
+    sum.len1 = (int64_t)hap_seq[0].size(); sum.len2 = (int64_t)hap_seq[1].size();
+
+    {   // score + approximation certificate (:933-1004) -- stdout only
+        auto split = [&](const std::vector<int> &cs, std::vector<int> &hom, std::vector<int> &het) {
+            for (auto c : cs) { if (color_homo_bv[c]) hom.push_back(c); else het.push_back(c); }
+            std::sort(hom.begin(), hom.end()); hom.erase(std::unique(hom.begin(), hom.end()), hom.end());
+            std::sort(het.begin(), het.end()); het.erase(std::unique(het.begin(), het.end()), het.end());
+        };
+        std::vector<int> h1, t1, h2, t2, inter, symd;
+        split(p_colors[0], h1, t1); split(p_colors[1], h2, t2);
+        std::set_intersection(h1.begin(), h1.end(), h2.begin(), h2.end(), std::back_inserter(inter));
+        std::set_symmetric_difference(t1.begin(), t1.end(), t2.begin(), t2.end(), std::back_inserter(symd));
+        int intersection_count = (int)inter.size(), symdiff_count = (int)symd.size();
+        int m_G_hom = 0, m_G_het = 0;
+        auto freq = [&](int which, int c) { auto it = p_color_freq[which].find(c); return it == p_color_freq[which].end() ? 0 : it->second; };
+        for (auto c : inter) { int k1 = freq(0, c), k2 = freq(1, c); m_G_hom += (k1 >= k2 ? k1 : k2); }
+        for (auto c : symd) m_G_het += freq(0, c) + freq(1, c);
+        float m_G_hom_avg = m_G_hom / (float)intersection_count;
+        float m_G_het_avg = m_G_het / (float)symdiff_count;
+        float m_bar = std::max(m_G_hom_avg, m_G_het_avg);
+        int loss_het = res.s_het - m_G_het;
+        float additive_term = loss_het / (float)m_G_het_avg;
+        int obj = intersection_count + symdiff_count;
+        sum.obj = obj;
+        if (!opt.quiet) {
+            std::cout << "r: " << R << " obj: " << obj << std::endl;
+            float ub = m_bar * (obj + additive_term);
+            std::cout << "Approximation certificate: multiplicative factor: " << ub / (float)obj << std::endl;
+        }
+    }
+    if (!opt.quiet)
+        std::cout << "recombinations in P1: " << r1 << ", recombinations in P2: " << r2 << ", bp of P1: " << hap_seq[0].length()
+                  << ", bp of P2: " << hap_seq[1].length() << std::endl;                 // :1307-1308
+    {
+        std::ofstream f(opt.hap_file, std::ios::out);                                    // :1314-1325
+        f << ">" << "sol_1" << " bp:" << hap_seq[0].size() << std::endl;
+        for (size_t i = 0; i < hap_seq[0].size(); i += 80) f << hap_seq[0].substr(i, 80) << std::endl;
+        f << ">" << "sol_2" << " bp:" << hap_seq[1].size() << std::endl;
+        for (size_t i = 0; i < hap_seq[1].size(); i += 80) f << hap_seq[1].substr(i, 80) << std::endl;
+        f.close();
+    }
+    stamp("traceback+write", t0);
+    return 0;
+}
+
+int Pipeline::run(std::string &err) {                                  // main.cpp:117-165
+    sum = Summary();
+    double t0 = now_s();
+    if (load_graph(err)) return -1;
+    if (opt.ploidy != 1 && opt.ploidy != 2) {
+        std::cout << "Current approximator support is only for ploidy = 1 or ploidy = 2" << std::endl;
+        return 0;
+    }
+    if (load_reads(err)) return -1;
+    if (compute_and_classify_anchors(err)) return -1;
+    if (solve(err)) return -1;
+    sum.stage_s.emplace_back("total", now_s() - t0);
+    return 0;
+}
+
+}  // namespace dg

@@ -1,0 +1,123 @@
+// Host-side mirror of the reference's Solver / Approximator objects for the diploid hot path.
+//
+// Everything that is NOT one of the two device loops stays here, restated so that vertex numbering,
+// adjacency order and every tie-break match the reference exactly:
+//   Solver::read_gfa                       /root/reference/src/solver.cpp:27-227
+//   Solver::compute_and_classify_anchors   /root/reference/src/solver.cpp:449-887
+//   Approximator::solve                    /root/reference/src/approximator.cpp:1014-1331
+//   ExpandedGraph::topologically_reorder   /root/reference/src/ExpandedGraph.hpp:29-102
+//   ExpandedGraph::strict_bfs_levelize_and_reorder   /root/reference/src/ExpandedGraph.hpp:269-409
+//   haploid dp_approximation_solver        /root/reference/src/approximator.cpp:44-168 (CPU by design)
+//   traceback -> sequences, certificate    /root/reference/src/approximator.cpp:720-1004
+// The two device loops are reached only through the Backend table (= include/dipgenie_hip.h).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/dipgenie_hip.h"
+#include "fitter.hpp"
+#include "gfa_reader.hpp"
+
+namespace dg {
+
+struct Backend {     // same signatures as the C ABI, plus an opaque ctx
+    void *ctx = nullptr;
+    int (*sketch_reads)(void *, const char *, const int64_t *, int64_t, int, int, uint64_t **, int32_t **, int64_t *) = nullptr;
+    int (*sketch_haplotype)(void *, const char *, int64_t, int, int, uint64_t **, int64_t **, int64_t *) = nullptr;
+    int (*dp_solve_diploid)(void *, const dg_dp_graph *, dg_dp_result *) = nullptr;
+    void (*free_buf)(void *) = nullptr;
+    const char *(*last_error)() = nullptr;
+};
+
+struct Options {
+    int threads = 4;          // -t
+    int ploidy = 2;           // -p
+    int R = 18;               // -R
+    int k = 31, w = 25;       // -k -w
+    float threshold = 1.0f;   // -T
+    bool debug = false;       // -d
+    bool quiet = false;       // (ours) suppress progress chatter
+    std::string gfa_file, reads_file, hap_file;   // -g -r -o
+    std::string dump_prefix;  // (ours) if set, dump the levelized DP graph to <prefix>.dpg
+};
+
+struct ExpandedGraph {        // ExpandedGraph.hpp:16-26
+    std::vector<int> level, haplotype;
+    std::vector<std::vector<int>> color, original_vertex, vertices_in_level;
+    std::vector<std::vector<std::pair<int, int>>> adj_list;
+    void topologically_reorder(int sink);
+    int strict_bfs_levelize_and_reorder();
+};
+
+struct AnchorRec {            // approximator.h:11-18
+    int startOrg, endOrg, startExp, endExp;
+    std::vector<int> colours;
+    int nodeID;
+};
+
+// Flattened levelized graph in dg_dp_graph layout (owning storage).
+struct DpGraphStorage {
+    std::vector<int32_t> level_off, out_dst, hom_col, het_col;
+    std::vector<int64_t> out_off, hom_off, het_off;
+    std::vector<uint8_t> out_w;
+    dg_dp_graph view(int R) const;
+    bool save(const std::string &path, int R) const;   // little-endian binary, see pipeline.cpp
+    bool load(const std::string &path, int &R);
+};
+
+struct Summary {              // what tests and the CLI report
+    int32_t dp_value = 0, s_het = 0, r1 = -1, r2 = -1, obj = 0, best_r_haploid = -1;
+    int64_t len1 = 0, len2 = 0;
+    int64_t spectrum = 0, n_levels = 0, n_vertices = 0, n_colours = 0;
+    uint64_t cells = 0, relaxations = 0;
+    std::vector<int64_t> minimizers_per_hap, anchors_per_hap;
+    KGFitResult fit;
+    std::vector<std::pair<std::string, double>> stage_s;
+};
+
+// One anchor occurrence: vertex list vpool[off, off+len) of read-minimizer id `a` on haplotype `h`.
+struct Occ { int32_t a, h; uint32_t off, len; };
+
+class Pipeline {
+  public:
+    Options opt;
+    Backend be;
+    Summary sum;
+
+    // ---- Solver state (solver.h:73-85) ----
+    uint32_t n_vtx = 0, num_walks = 0;
+    std::vector<std::vector<uint32_t>> adj_list;
+    std::vector<std::string> node_seq;
+    std::vector<std::vector<uint32_t>> paths;
+    std::vector<int32_t> top_order_map;
+    std::vector<std::string> hap_id2name;
+    std::vector<std::pair<std::string, std::string>> reads;
+    int32_t count_sp_r = 0;
+    // Anchor_hits[a][h] flattened: occs sorted by (a, h, final occurrence order)
+    std::vector<Occ> occs;
+    std::vector<int32_t> vpool;
+    std::vector<uint8_t> homo_bv;          // per read-minimizer id
+
+    int load_graph(std::string &err);      // gfa_read + Solver::read_gfa
+    int load_reads(std::string &err);      // Solver::read_ip_reads
+    int compute_and_classify_anchors(std::string &err);
+    int solve(std::string &err);           // Approximator::solve (writes the FASTA)
+    int run(std::string &err);             // main.cpp:117-165
+
+    // exposed for tests
+    DpGraphStorage dpg;
+
+  private:
+    void read_gfa_from(const GfaGraph &g);
+    std::vector<int> haploid_dp(const ExpandedGraph &g, int R);
+    int diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
+                const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err);
+    void stamp(const char *name, double t0);
+};
+
+double now_s();
+
+}  // namespace dg

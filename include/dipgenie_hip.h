@@ -1,0 +1,123 @@
+/* include/dipgenie_hip.h -- C ABI of libdipgenie_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for DipGenie's diploid hot path.  The reference has no FFI/plugin layer; the
+ * seams these entry points replace are C++ member calls (all citations relative to the reference):
+ *
+ *   dg_dp_solve_diploid     replaces the level loop + sink read-out of
+ *                           Approximator::diploid_dp_approximation_solver
+ *                           (src/approximator.h:26, src/approximator.cpp:532-716 and :757-785)
+ *   dg_sketch_reads         replaces the per-read Solver::compute_hashes loop and the Sp_R /
+ *                           kmer_count maps (src/solver.h:101, src/solver.cpp:526-546, 711-732)
+ *   dg_sketch_haplotype     replaces the window loop of Solver::index_kmers
+ *                           (src/solver.h:100, src/solver.cpp:302-361); the position -> vertex-span
+ *                           mapping (:343-357) stays in the host code
+ *   dg_hash_kmers           exposes hash128_to_64_ (src/solver.cpp:16-24) for known-answer tests
+ *
+ * Conventions: plain pointers and sizes only; `int` return (0 = ok, <0 = error, message from
+ * dg_last_error()); no exceptions cross the boundary; one dg_ctx <-> one HIP device + stream; a ctx
+ * is not thread-safe, different ctxs are independent.  "host" pointers are ordinary process memory;
+ * "_dev" entry points take device pointers (e.g. torch tensors' data_ptr()) and run on the ctx
+ * stream without synchronising unless stated.  There is NO CPU fallback: every entry point fails
+ * with DG_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DIPGENIE_HIP_H
+#define DIPGENIE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_OK              0
+#define DG_ERR_ARG        -1
+#define DG_ERR_NO_DEVICE  -2
+#define DG_ERR_HIP        -3
+#define DG_ERR_OOM        -4
+#define DG_ERR_UNSUPPORTED -5
+#define DG_ERR_STATE      -6
+
+typedef struct dg_ctx dg_ctx;
+
+/* ---- context ---- */
+dg_ctx     *dg_create(int device);                 /* NULL on failure (see dg_last_error) */
+void        dg_destroy(dg_ctx *);
+const char *dg_last_error(void);                   /* thread-local message of the last failure */
+int         dg_set_stream(dg_ctx *, void *hip_stream);   /* adopt an external hipStream_t (e.g. torch's) */
+int         dg_synchronize(dg_ctx *);
+int         dg_device_info(dg_ctx *, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes);
+
+/* ---- diploid pair-of-paths DP ---- */
+typedef struct dg_dp_graph {          /* levelized expanded graph, vertex ids already level-sorted */
+    int32_t n_vertices, n_levels, R;
+    const int32_t *level_off;         /* [n_levels+1]; level 0 = {source}, last level = {sink} */
+    const int64_t *out_off;           /* [n_vertices+1] out-CSR, adjacency order preserved */
+    const int32_t *out_dst;           /* every edge goes from level l to level l+1 */
+    const uint8_t *out_w;             /* recombination weight 0/1 */
+    const int64_t *hom_off, *het_off; /* [n_vertices+1] sorted-unique colour CSR (HOM / HET colours) */
+    const int32_t *hom_col, *het_col;
+} dg_dp_graph;
+
+typedef struct dg_dp_result {         /* sink state at r = R (approximator.cpp:774-785) */
+    int32_t value, s_het, n_p1, n_p2;
+    int32_t *p1_from, *p1_to, *p2_from, *p2_to;   /* caller-provided, capacity `cap` each (>= R+2) */
+    int32_t cap;
+    uint64_t cells, relaxations;      /* work counters: sum k^2(R+1), sum (sum outdeg)^2 (R+1) */
+} dg_dp_result;
+
+typedef struct dg_dp_timing {         /* HIP-event times of the last dg_dp_run, milliseconds */
+    float delta_ms;                   /* score-delta precompute kernel(s) */
+    float forward_ms;                 /* level sweep */
+    float traceback_ms;               /* back-pointer walk + edge-list extraction */
+    float total_ms;                   /* first launch -> last kernel done */
+    int64_t n_forward_launches;
+    uint64_t edge_pairs;              /* sum over levels of (in-edges into level)^2 */
+    uint64_t colour_entries;          /* colour list entries read by the delta kernel */
+    uint64_t state_bytes, bp_bytes, delta_bytes;   /* device allocations */
+} dg_dp_timing;
+
+int dg_dp_load_graph(dg_ctx *, const dg_dp_graph *);   /* validate + upload + build in-CSR; resident until next load */
+int dg_dp_run(dg_ctx *, dg_dp_result *);               /* all kernels on the resident graph; synchronises */
+int dg_dp_get_timing(dg_ctx *, dg_dp_timing *);
+int dg_dp_solve_diploid(dg_ctx *, const dg_dp_graph *, dg_dp_result *);   /* = load_graph + run */
+/* debug/parity: copy the per-level digest (same definition as the oracle's level_digest) of the
+ * last run; out has n_levels entries, entry 0 unused. Requires dg_dp_set_option("digest",1). */
+int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
+int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
+
+/* ---- (w,k)-minimizer sketching ---- */
+/* reads: concatenated bases + offsets [n_reads+1] (host). Outputs (malloc'ed by the library, release
+ * with dg_free): globally sorted distinct minimizer hashes and the number of reads containing each
+ * (== Sp_R keys in order / kmer_count values). */
+int dg_sketch_reads(dg_ctx *, const char *bases, const int64_t *read_off, int64_t n_reads, int k, int w,
+                    uint64_t **hash, int32_t **n_reads_with_hash, int64_t *n_distinct);
+/* one haplotype string (host): the emitted-on-hash-change minimizer list in sequence order.
+ * pos = start of the winning k-mer. Outputs malloc'ed by the library (dg_free). */
+int dg_sketch_haplotype(dg_ctx *, const char *seq, int64_t len, int k, int w,
+                        uint64_t **hash, int64_t **pos, int64_t *n);
+/* hash n k-mers of length k stored back to back (host) with h1^h2 of MurmurHash3_x64_128, seed 0 */
+int dg_hash_kmers(dg_ctx *, const char *kmers, int64_t n, int k, uint64_t *out);
+void dg_free(void *);
+
+typedef struct dg_sketch_timing { float kernel_ms, sort_ms, total_ms; int64_t n_emitted; } dg_sketch_timing;
+int dg_sketch_get_timing(dg_ctx *, dg_sketch_timing *);
+
+/* Device-resident variants for the read-sharded multi-GPU path (one rank per GPU; collectives are
+ * done by the caller over RCCL on the same buffers).
+ *  dg_sketch_reads_dev: bases/read_off are DEVICE pointers; writes up to cap distinct (hash,count)
+ *  pairs of THIS shard, sorted by hash, into device buffers; *n_distinct on host. Synchronises. */
+int dg_sketch_reads_dev(dg_ctx *, const char *bases_dev, const int64_t *read_off_dev, int64_t n_reads,
+                        int64_t n_bases, int k, int w, uint64_t *hash_dev, int32_t *count_dev, int64_t cap,
+                        int64_t *n_distinct);
+/* counts_dev[i] += count of dict_dev[i] in the shard's (hash,count) list (both sorted); the caller
+ * then all-reduces counts_dev (uint32 per dictionary minimizer). Asynchronous on the ctx stream. */
+int dg_sketch_count_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n_dict,
+                                   const uint64_t *hash_dev, const int32_t *count_dev, int64_t n,
+                                   int32_t *counts_dev);
+/* merge several sorted (hash,count) runs stored back to back (device) into one sorted distinct
+ * list with summed counts (device, capacity cap). Synchronises. */
+int dg_sketch_merge_runs_dev(dg_ctx *, const uint64_t *hash_dev, const int32_t *count_dev, int64_t n_total,
+                             uint64_t *out_hash_dev, int32_t *out_count_dev, int64_t cap, int64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+// tests/harness/dg_host_oracle.cpp -- TEST HARNESS (not product).
+//
+// Runs the product's host pipeline (dipgenie_amd/host) with the two device loops supplied by the CPU
+// oracle (oracle/liboracle.so) instead of libdipgenie_hip.so.  Purpose: prove, on a machine without
+// a GPU, that the HOST stages (GFA reader, read_gfa order, anchors/filter, fit/classify, expanded
+// graph, levelize, traceback, FASTA writer) reproduce the reference byte-for-byte, and dump the
+// levelized DP graph (.dpg) that the GPU parity tests feed to both the oracle and the HIP path.
+// Same flags as the product CLI, plus -D <prefix> (dump) and -J <file> (JSON summary).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unistd.h>
+
+#include "../../dipgenie_amd/host/pipeline.hpp"
+#include "../../oracle/oracle.h"
+
+static int o_sketch_reads(void *, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **c, int64_t *nd) {
+    return orc_sketch_reads(b, off, n, k, w, h, c, nd);
+}
+static int o_sketch_hap(void *, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) {
+    int64_t cnt = orc_minimizers(s, len, k, w, nullptr, nullptr, 0);
+    *h = (uint64_t *)malloc(sizeof(uint64_t) * (cnt + 1));
+    *p = (int64_t *)malloc(sizeof(int64_t) * (cnt + 1));
+    *n = orc_minimizers(s, len, k, w, *h, *p, cnt);
+    return 0;
+}
+static int o_dp(void *, const dg_dp_graph *g, dg_dp_result *r) {
+    static_assert(sizeof(orc_dp_graph) == sizeof(dg_dp_graph), "layout");
+    static_assert(sizeof(orc_dp_result) == sizeof(dg_dp_result), "layout");
+    return orc_dp_solve_diploid((const orc_dp_graph *)g, (orc_dp_result *)r, nullptr);
+}
+static const char *o_err() { return "oracle"; }
+
+int main(int argc, char **argv) {
+    dg::Pipeline p;
+    std::string json;
+    int c;
+    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:q")) >= 0) {
+        switch (c) {
+        case 't': p.opt.threads = atoi(optarg); break;
+        case 'p': p.opt.ploidy = atoi(optarg); break;
+        case 'R': p.opt.R = atoi(optarg); break;
+        case 'g': p.opt.gfa_file = optarg; break;
+        case 'r': p.opt.reads_file = optarg; break;
+        case 'o': p.opt.hap_file = optarg; break;
+        case 'k': p.opt.k = atoi(optarg); break;
+        case 'w': p.opt.w = atoi(optarg); break;
+        case 'T': p.opt.threshold = (float)atof(optarg); break;
+        case 'd': p.opt.debug = atoi(optarg); break;
+        case 'D': p.opt.dump_prefix = optarg; break;
+        case 'J': json = optarg; break;
+        case 'q': p.opt.quiet = true; break;
+        }
+    }
+    p.be.sketch_reads = o_sketch_reads;
+    p.be.sketch_haplotype = o_sketch_hap;
+    p.be.dp_solve_diploid = o_dp;
+    p.be.free_buf = orc_free;
+    p.be.last_error = o_err;
+    std::string err;
+    if (p.run(err) != 0) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    if (!json.empty()) {
+        FILE *f = fopen(json.c_str(), "w");
+        fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "
+                   "\"spectrum\": %lld, \"n_levels\": %lld, \"n_vertices\": %lld, \"cells\": %llu, \"relaxations\": %llu, "
+                   "\"best_r_haploid\": %d, \"fit_nll\": %.17g}\n",
+                p.sum.dp_value, p.sum.s_het, p.sum.r1, p.sum.r2, p.sum.obj, (long long)p.sum.len1, (long long)p.sum.len2,
+                (long long)p.sum.spectrum, (long long)p.sum.n_levels, (long long)p.sum.n_vertices,
+                (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll);
+        fclose(f);
+    }
+    return 0;
+}
