@@ -1,0 +1,490 @@
+// libdipgenie_hip.so -- (w,k)-minimizer sketching for MI355X (gfx950).
+//
+// Replaces the window loops of Solver::index_kmers / Solver::compute_hashes and the Sp_R /
+// kmer_count maps (/root/reference/src/solver.cpp:302-361, 374-409, 526-546, 711-732).
+// Semantics kept exactly: sequences are upper-cased; the canonical k-mer is the
+// ASCII-lexicographic min of the k-mer and its reverse complement (non-ACGT bytes pass through the
+// complement and order as ASCII); the window minimum takes the NEWEST on ties; a minimizer is
+// emitted when its hash differs from the previous window's; hash = h1^h2 of MurmurHash3_x64_128 over
+// the k ASCII bytes, seed 0 (restated from the published algorithm).
+//
+// Kernel shape: one wave (64 lanes) per tile of <=128 windows, 4 tiles per 256-thread workgroup.
+// The tile's bases are staged once in LDS; every lane builds 2-bit codes for its k-mers (valid for
+// pure-ACGT k-mers, k<=32, where 2-bit order == ASCII order), scans its windows, and hashes only
+// window minima whose position changed. K-mers containing other bytes fall to an in-kernel bytewise
+// comparison -- same result, no host fallback. Emission is two-pass (count, scan, write) so output
+// order is deterministic; the per-read set semantics and the global spectrum come from one stable
+// radix sort by hash + a (hash,read) run flag + reduce_by_key (rocPRIM primitives).
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "dg_internal.hpp"
+
+namespace dgi {
+
+constexpr int TW = 128;                 // windows per tile (2 per lane)
+
+struct Tile {
+    int64_t seq_start;                  // offset of the sequence in the bases buffer
+    int32_t seq_len;
+    int32_t win0;                       // first window of the tile (window i covers k-mers i .. i+w-1)
+    int32_t nwin;
+    int32_t seq_id;
+};
+
+struct SketchState {
+    DevBuf d_bases, d_off, d_tiles, d_tile_cnt, d_tile_base, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n,
+        d_pos, d_kmers, d_out;
+    dg_sketch_timing timing;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+void sketch_state_free(SketchState *s) {
+    if (!s) return;
+    for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+// ------------------------------------------------------------------ MurmurHash3_x64_128 (h1^h2)
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k;
+}
+// G(t) returns byte t of the key
+template <class G>
+__device__ __forceinline__ uint64_t murmur3_fold(G byte_at, int len) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = 0, h2 = 0;            // seed 0
+    const int nblocks = len >> 4;
+    for (int b = 0; b < nblocks; ++b) {
+        uint64_t k1 = 0, k2 = 0;
+        for (int t = 0; t < 8; ++t) k1 |= (uint64_t)byte_at(16 * b + t) << (8 * t);
+        for (int t = 0; t < 8; ++t) k2 |= (uint64_t)byte_at(16 * b + 8 + t) << (8 * t);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const int tail = nblocks << 4, rem = len & 15;
+    uint64_t k1 = 0, k2 = 0;
+    for (int t = 8; t < rem; ++t) k2 |= (uint64_t)byte_at(tail + t) << (8 * (t - 8));
+    if (rem > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    for (int t = 0; t < rem && t < 8; ++t) k1 |= (uint64_t)byte_at(tail + t) << (8 * t);
+    if (rem > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h1 ^ h2;                     // solver.cpp:23
+}
+
+__device__ __forceinline__ uint8_t upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+__device__ __forceinline__ uint8_t comp(uint8_t c) {    // misc.cpp:103-115 on upper-cased input
+    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+__device__ __forceinline__ int code2(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+// byte t of the canonical k-mer starting at LDS offset p (orientation o: 1 = reverse complement)
+__device__ __forceinline__ uint8_t canon_byte(const uint8_t *s, int p, int k, int o, int t) {
+    return o ? comp(s[p + k - 1 - t]) : s[p + t];
+}
+__device__ __forceinline__ int cmp_canon(const uint8_t *s, int k, int p, int op, int q, int oq) {
+    for (int t = 0; t < k; ++t) {
+        const uint8_t a = canon_byte(s, p, k, op, t), b = canon_byte(s, q, k, oq, t);
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ tile kernel
+// MODE 0: count emissions per tile; MODE 1: write hashes (+ aux: seq_id for reads, position for haplotypes)
+template <int MODE, bool AUX_IS_POS>
+__global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict__ bases, const Tile *__restrict__ tiles,
+                                                          int64_t n_tiles, int k, int w, int64_t *__restrict__ tile_cnt,
+                                                          const int64_t *__restrict__ tile_base, uint64_t *__restrict__ out_hash,
+                                                          int64_t *__restrict__ out_aux, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const bool active = tile_id < n_tiles;              // inactive waves only take part in the barriers
+    Tile T{0, 0, 0, 0, 0};
+    if (active) T = tiles[tile_id];
+    const int has_prev = T.win0 > 0 ? 1 : 0;
+    const int km0 = T.win0 - has_prev;                  // first k-mer (sequence coordinate) needed
+    const int nkm = active ? T.nwin + has_prev + w - 1 : 0;   // k-mers needed
+    const int nb = active ? nkm + k - 1 : 0;            // bases needed
+    unsigned char *base = smem + (size_t)wave * lds_per_wave;
+    uint64_t *code = (uint64_t *)base;                                 // [TW + w]
+    int32_t *wpos = (int32_t *)(code + (TW + w));                      // [TW + 1] argmin k-mer (tile-local) per window
+    uint8_t *info = (uint8_t *)(wpos + (TW + 1));                      // [TW + w] bit0 valid, bit1 orientation
+    uint8_t *sq = info + (TW + w);                                     // [TW + w + k]
+
+    const char *src = bases + T.seq_start + km0;
+    for (int t = lane; t < nb; t += 64) sq[t] = upper((uint8_t)src[t]);
+    __syncthreads();
+
+    // canonical 2-bit code / orientation per k-mer (first base most significant: integer order ==
+    // lexicographic order; A<C<G<T matches ASCII)
+    for (int q = lane; q < nkm; q += 64) {
+        uint64_t f = 0, r = 0;
+        bool valid = (k <= 32);
+        if (valid) {
+            for (int t = 0; t < k; ++t) {
+                const int cf = code2(sq[q + t]);
+                if (cf < 0) { valid = false; break; }
+                f = (f << 2) | (uint64_t)cf;
+                r |= (uint64_t)(3 - cf) << (2 * t);     // reverse complement, same significance convention
+            }
+        }
+        int o;
+        if (valid) {
+            o = r < f ? 1 : 0;
+            code[q] = o ? r : f;
+        } else {
+            o = cmp_canon(sq, k, q, 1, q, 0) < 0 ? 1 : 0;   // rc < fwd, bytewise
+            code[q] = 0;
+        }
+        info[q] = (uint8_t)((valid ? 1 : 0) | (o << 1));
+    }
+    __syncthreads();
+
+    // window minima (ties -> newest, solver.cpp:316)
+    const int nw_all = active ? T.nwin + has_prev : 0;
+    for (int wi = lane; wi < nw_all; wi += 64) {
+        int best = wi;
+        bool allv = true;
+        for (int t = 0; t < w; ++t) allv = allv && (info[wi + t] & 1);
+        if (allv) {
+            uint64_t bc = code[wi];
+            for (int t = 1; t < w; ++t) { const uint64_t c = code[wi + t]; if (c <= bc) { bc = c; best = wi + t; } }
+        } else {
+            for (int t = 1; t < w; ++t)
+                if (cmp_canon(sq, k, wi + t, (info[wi + t] >> 1) & 1, best, (info[best] >> 1) & 1) <= 0) best = wi + t;
+        }
+        wpos[wi] = best;
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // emission (solver.cpp:329-335 / 401-407)
+    int64_t wbase = MODE == 1 ? tile_base[tile_id] : 0;
+    int64_t total = 0;
+    for (int round = 0; round * 64 < T.nwin; ++round) {
+        const int wi = round * 64 + lane;                // tile-local window (without the prev offset)
+        bool emit = false;
+        uint64_t H = 0;
+        int p = 0;
+        if (wi < T.nwin) {
+            p = wpos[wi + has_prev];
+            const int op = (info[p] >> 1) & 1;
+            auto bp = [&](int t) -> uint8_t { return canon_byte(sq, p, k, op, t); };
+            if (T.win0 + wi == 0) {                      // first window of the sequence: prev_hash = UINT64_MAX
+                H = murmur3_fold(bp, k);
+                emit = H != UINT64_MAX;
+            } else {
+                const int q = wpos[wi + has_prev - 1];
+                if (q != p) {
+                    const int oq = (info[q] >> 1) & 1;
+                    auto bq = [&](int t) -> uint8_t { return canon_byte(sq, q, k, oq, t); };
+                    H = murmur3_fold(bp, k);
+                    emit = H != murmur3_fold(bq, k);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(emit);
+        if (MODE == 1 && emit) {
+            const int64_t slot = wbase + total + __popcll(m & ((1ULL << lane) - 1ULL));
+            out_hash[slot] = H;
+            out_aux[slot] = AUX_IS_POS ? (int64_t)(km0 + p) : (int64_t)T.seq_id;
+        }
+        total += __popcll(m);
+    }
+    if (MODE == 0 && lane == 0) tile_cnt[tile_id] = total;
+}
+
+__global__ void pair_flag_kernel(const uint64_t *__restrict__ hash, const int64_t *__restrict__ seq, int64_t n, int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || hash[i] != hash[i - 1] || seq[i] != seq[i - 1]) ? 1 : 0;   // one per distinct (hash, read)
+}
+
+__global__ void hash_kmers_kernel(const char *__restrict__ kmers, int64_t n, int k, uint64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *s = (const unsigned char *)kmers + i * k;
+    auto b = [&](int t) -> uint8_t { return s[t]; };
+    out[i] = murmur3_fold(b, k);
+}
+
+__global__ void dict_count_kernel(const uint64_t *__restrict__ dict, int64_t n_dict, const uint64_t *__restrict__ hash,
+                                  const int32_t *__restrict__ cnt, int64_t n, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dict) return;
+    const uint64_t key = dict[i];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hash[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < n && hash[lo] == key) out[i] += cnt[lo];
+}
+
+// ------------------------------------------------------------------ host side
+static SketchState &state(dg_ctx *c) {
+    if (!c->sk) c->sk = new SketchState();
+    return *c->sk;
+}
+
+static size_t lds_per_wave(int k, int w) {
+    size_t b = 8 * (size_t)(TW + w) + 4 * (size_t)(TW + 1) + (size_t)(TW + w) + (size_t)(TW + w + k);
+    return (b + 15) & ~(size_t)15;
+}
+
+static void make_tiles(const int64_t *off, int64_t n_seq, int k, int w, std::vector<Tile> &tiles) {
+    tiles.clear();
+    for (int64_t s = 0; s < n_seq; ++s) {
+        const int64_t len = off[s + 1] - off[s];
+        const int64_t nwin = len - k - w + 2;           // solver.cpp:291 / 372: nothing if len < w+k-1
+        for (int64_t w0 = 0; w0 < nwin; w0 += TW)
+            tiles.push_back(Tile{off[s], (int32_t)len, (int32_t)w0, (int32_t)std::min<int64_t>(TW, nwin - w0), (int32_t)s});
+    }
+}
+
+// Runs the two-pass tile kernel over device-resident bases. On return d_hash/d_aux hold n_emit entries.
+template <bool AUX_IS_POS>
+static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &tiles, int k, int w, int64_t *n_emit) {
+    SketchState &S = state(c);
+    hipStream_t s = c->stream;
+    const int64_t nt = (int64_t)tiles.size();
+    *n_emit = 0;
+    if (nt == 0) return DG_OK;
+    if (int rc = S.d_tiles.ensure(sizeof(Tile) * nt)) return rc;
+    DG_HIP(hipMemcpyAsync(S.d_tiles.p, tiles.data(), sizeof(Tile) * nt, hipMemcpyHostToDevice, s));
+    if (int rc = S.d_tile_cnt.ensure(8 * (nt + 1))) return rc;
+    if (int rc = S.d_tile_base.ensure(8 * (nt + 1))) return rc;
+    const size_t lpw = lds_per_wave(k, w);
+    const unsigned grid = (unsigned)((nt + 3) / 4);
+    hipLaunchKernelGGL((sketch_tile_kernel<0, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       S.d_tile_cnt.as<int64_t>(), (const int64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr, (int)lpw);
+    // exclusive scan of counts (as int64) -> tile_base; total at [nt]
+    DG_HIP(hipMemsetAsync((char *)S.d_tile_cnt.p + 8 * nt, 0, 8, s));
+    size_t tb = 0;
+    const int64_t *in = S.d_tile_cnt.as<int64_t>();
+    DG_HIP(rocprim::exclusive_scan(nullptr, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
+    int64_t total = 0;
+    DG_HIP(hipMemcpyAsync(&total, S.d_tile_base.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipStreamSynchronize(s));
+    *n_emit = total;
+    if (total == 0) return DG_OK;
+    if (int rc = S.d_hash.ensure(8 * total)) return rc;
+    if (int rc = S.d_aux.ensure(8 * total)) return rc;
+    hipLaunchKernelGGL((sketch_tile_kernel<1, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       (int64_t *)nullptr, S.d_tile_base.as<int64_t>(), S.d_hash.as<uint64_t>(), S.d_aux.as<int64_t>(), (int)lpw);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+// (hash, read) pairs in d_hash/d_aux -> sorted distinct hashes + #reads in d_uniq/d_cnt; returns n_distinct
+static int spectrum_from_pairs(dg_ctx *c, int64_t n, int64_t *n_distinct) {
+    SketchState &S = state(c);
+    hipStream_t s = c->stream;
+    *n_distinct = 0;
+    if (n == 0) return DG_OK;
+    if (int rc = S.d_hash2.ensure(8 * n)) return rc;
+    if (int rc = S.d_aux2.ensure(8 * n)) return rc;
+    size_t tb = 0;
+    DG_HIP(rocprim::radix_sort_pairs(nullptr, tb, S.d_hash.as<uint64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux.as<int64_t>(),
+                                     S.d_aux2.as<int64_t>(), (size_t)n, 0, 64, s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::radix_sort_pairs(S.d_tmp.p, tb, S.d_hash.as<uint64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux.as<int64_t>(),
+                                     S.d_aux2.as<int64_t>(), (size_t)n, 0, 64, s));
+    if (int rc = S.d_flag.ensure(4 * n)) return rc;
+    hipLaunchKernelGGL(pair_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), n,
+                       S.d_flag.as<int32_t>());
+    if (int rc = S.d_uniq.ensure(8 * n)) return rc;
+    if (int rc = S.d_cnt.ensure(4 * n)) return rc;
+    if (int rc = S.d_n.ensure(8)) return rc;
+    DG_HIP(rocprim::reduce_by_key(nullptr, tb, S.d_hash2.as<uint64_t>(), S.d_flag.as<int32_t>(), (size_t)n, S.d_uniq.as<uint64_t>(),
+                                  S.d_cnt.as<int32_t>(), S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(),
+                                  rocprim::equal_to<uint64_t>(), s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::reduce_by_key(S.d_tmp.p, tb, S.d_hash2.as<uint64_t>(), S.d_flag.as<int32_t>(), (size_t)n, S.d_uniq.as<uint64_t>(),
+                                  S.d_cnt.as<int32_t>(), S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(),
+                                  rocprim::equal_to<uint64_t>(), s));
+    unsigned long long nd = 0;
+    DG_HIP(hipMemcpyAsync(&nd, S.d_n.p, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipStreamSynchronize(s));
+    *n_distinct = (int64_t)nd;
+    return DG_OK;
+}
+
+static int check_kw(int k, int w) {
+    if (k < 1 || k > 255 || w < 1 || w > 255) { set_error("k and w must be in 1..255 (k=%d w=%d)", k, w); return DG_ERR_ARG; }
+    return DG_OK;
+}
+
+static int events(SketchState &S) {
+    for (auto &e : S.ev) if (!e) DG_HIP(hipEventCreate(&e));
+    return DG_OK;
+}
+
+static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *off_host, int64_t n_reads, int k, int w, int64_t *n_distinct) {
+    SketchState &S = state(c);
+    if (int rc = events(S)) return rc;
+    std::vector<Tile> tiles;
+    make_tiles(off_host, n_reads, k, w, tiles);
+    DG_HIP(hipEventRecord(S.ev[0], c->stream));
+    int64_t n_emit = 0;
+    if (int rc = run_tiles<false>(c, bases_dev, tiles, k, w, &n_emit)) return rc;
+    DG_HIP(hipEventRecord(S.ev[1], c->stream));
+    if (int rc = spectrum_from_pairs(c, n_emit, n_distinct)) return rc;
+    DG_HIP(hipEventRecord(S.ev[2], c->stream));
+    DG_HIP(hipStreamSynchronize(c->stream));
+    DG_HIP(hipEventElapsedTime(&S.timing.kernel_ms, S.ev[0], S.ev[1]));
+    DG_HIP(hipEventElapsedTime(&S.timing.sort_ms, S.ev[1], S.ev[2]));
+    DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[2]));
+    S.timing.n_emitted = n_emit;
+    return DG_OK;
+}
+
+}  // namespace dgi
+
+using namespace dgi;
+
+extern "C" int dg_sketch_reads(dg_ctx *c, const char *bases, const int64_t *read_off, int64_t n_reads, int k, int w,
+                               uint64_t **hash, int32_t **cnt, int64_t *n_distinct) {
+    if (int rc = bind(c)) return rc;
+    if (int rc = check_kw(k, w)) return rc;
+    if (!read_off || !hash || !cnt || !n_distinct || n_reads < 0) { set_error("dg_sketch_reads: bad arguments"); return DG_ERR_ARG; }
+    SketchState &S = state(c);
+    const int64_t nb = n_reads ? read_off[n_reads] : 0;
+    if (int rc = S.d_bases.ensure((size_t)nb + 16)) return rc;
+    if (nb) DG_HIP(hipMemcpyAsync(S.d_bases.p, bases, (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    int64_t nd = 0;
+    if (int rc = sketch_reads_device(c, S.d_bases.as<char>(), read_off, n_reads, k, w, &nd)) return rc;
+    *hash = (uint64_t *)malloc(8 * (size_t)(nd + 1));
+    *cnt = (int32_t *)malloc(4 * (size_t)(nd + 1));
+    if (!*hash || !*cnt) { set_error("host malloc failed"); return DG_ERR_OOM; }
+    if (nd) {
+        DG_HIP(hipMemcpyAsync(*hash, S.d_uniq.p, 8 * (size_t)nd, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipMemcpyAsync(*cnt, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipStreamSynchronize(c->stream));
+    }
+    *n_distinct = nd;
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_reads_dev(dg_ctx *c, const char *bases_dev, const int64_t *read_off_dev, int64_t n_reads, int64_t n_bases,
+                                   int k, int w, uint64_t *hash_dev, int32_t *count_dev, int64_t cap, int64_t *n_distinct) {
+    if (int rc = bind(c)) return rc;
+    if (int rc = check_kw(k, w)) return rc;
+    if (!bases_dev || !read_off_dev || !n_distinct || n_reads < 0) { set_error("dg_sketch_reads_dev: bad arguments"); return DG_ERR_ARG; }
+    (void)n_bases;
+    std::vector<int64_t> off((size_t)n_reads + 1);
+    DG_HIP(hipMemcpyAsync(off.data(), read_off_dev, 8 * off.size(), hipMemcpyDeviceToHost, c->stream));
+    DG_HIP(hipStreamSynchronize(c->stream));
+    int64_t nd = 0;
+    if (int rc = sketch_reads_device(c, bases_dev, off.data(), n_reads, k, w, &nd)) return rc;
+    if (nd > cap) { set_error("dg_sketch_reads_dev: %lld distinct hashes exceed capacity %lld", (long long)nd, (long long)cap); return DG_ERR_ARG; }
+    SketchState &S = state(c);
+    if (nd) {
+        DG_HIP(hipMemcpyAsync(hash_dev, S.d_uniq.p, 8 * (size_t)nd, hipMemcpyDeviceToDevice, c->stream));
+        DG_HIP(hipMemcpyAsync(count_dev, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToDevice, c->stream));
+        DG_HIP(hipStreamSynchronize(c->stream));
+    }
+    *n_distinct = nd;
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_haplotype(dg_ctx *c, const char *seq, int64_t len, int k, int w, uint64_t **hash, int64_t **pos, int64_t *n) {
+    if (int rc = bind(c)) return rc;
+    if (int rc = check_kw(k, w)) return rc;
+    if (!hash || !pos || !n || len < 0) { set_error("dg_sketch_haplotype: bad arguments"); return DG_ERR_ARG; }
+    if (len >= ((int64_t)1 << 31)) { set_error("sequence longer than 2^31 bases is not supported"); return DG_ERR_UNSUPPORTED; }
+    SketchState &S = state(c);
+    if (int rc = events(S)) return rc;
+    if (int rc = S.d_bases.ensure((size_t)len + 16)) return rc;
+    if (len) DG_HIP(hipMemcpyAsync(S.d_bases.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
+    int64_t off[2] = {0, len};
+    std::vector<Tile> tiles;
+    make_tiles(off, 1, k, w, tiles);
+    DG_HIP(hipEventRecord(S.ev[0], c->stream));
+    int64_t ne = 0;
+    if (int rc = run_tiles<true>(c, S.d_bases.as<char>(), tiles, k, w, &ne)) return rc;
+    DG_HIP(hipEventRecord(S.ev[1], c->stream));
+    *hash = (uint64_t *)malloc(8 * (size_t)(ne + 1));
+    *pos = (int64_t *)malloc(8 * (size_t)(ne + 1));
+    if (!*hash || !*pos) { set_error("host malloc failed"); return DG_ERR_OOM; }
+    if (ne) {
+        DG_HIP(hipMemcpyAsync(*hash, S.d_hash.p, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipMemcpyAsync(*pos, S.d_aux.p, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+    }
+    DG_HIP(hipStreamSynchronize(c->stream));
+    DG_HIP(hipEventElapsedTime(&S.timing.kernel_ms, S.ev[0], S.ev[1]));
+    S.timing.sort_ms = 0; S.timing.total_ms = S.timing.kernel_ms; S.timing.n_emitted = ne;
+    *n = ne;
+    return DG_OK;
+}
+
+extern "C" int dg_hash_kmers(dg_ctx *c, const char *kmers, int64_t n, int k, uint64_t *out) {
+    if (int rc = bind(c)) return rc;
+    if (k < 1 || k > 255 || n < 0 || !out) { set_error("dg_hash_kmers: bad arguments"); return DG_ERR_ARG; }
+    if (n == 0) return DG_OK;
+    SketchState &S = state(c);
+    if (int rc = S.d_kmers.ensure((size_t)n * k)) return rc;
+    if (int rc = S.d_out.ensure(8 * (size_t)n)) return rc;
+    DG_HIP(hipMemcpyAsync(S.d_kmers.p, kmers, (size_t)n * k, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(hash_kmers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, S.d_kmers.as<char>(), n, k, S.d_out.as<uint64_t>());
+    DG_HIP(hipMemcpyAsync(out, S.d_out.p, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    DG_HIP(hipStreamSynchronize(c->stream));
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_get_timing(dg_ctx *c, dg_sketch_timing *t) {
+    if (!c || !c->sk || !t) { set_error("dg_sketch_get_timing: no state"); return DG_ERR_STATE; }
+    *t = c->sk->timing;
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_count_dictionary_dev(dg_ctx *c, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev,
+                                              const int32_t *count_dev, int64_t n, int32_t *counts_dev) {
+    if (int rc = bind(c)) return rc;
+    if (n_dict <= 0) return DG_OK;
+    hipLaunchKernelGGL(dict_count_kernel, dim3((unsigned)((n_dict + 255) / 256)), dim3(256), 0, c->stream, dict_dev, n_dict, hash_dev, count_dev, n, counts_dev);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_merge_runs_dev(dg_ctx *c, const uint64_t *hash_dev, const int32_t *count_dev, int64_t n, uint64_t *out_hash_dev,
+                                        int32_t *out_count_dev, int64_t cap, int64_t *n_out) {
+    if (int rc = bind(c)) return rc;
+    if (!n_out) { set_error("dg_sketch_merge_runs_dev: null n_out"); return DG_ERR_ARG; }
+    *n_out = 0;
+    if (n == 0) return DG_OK;
+    SketchState &S = state(c);
+    hipStream_t s = c->stream;
+    if (int rc = S.d_hash2.ensure(8 * n)) return rc;
+    if (int rc = S.d_flag.ensure(4 * n)) return rc;
+    size_t tb = 0;
+    DG_HIP(rocprim::radix_sort_pairs(nullptr, tb, hash_dev, S.d_hash2.as<uint64_t>(), count_dev, S.d_flag.as<int32_t>(), (size_t)n, 0, 64, s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::radix_sort_pairs(S.d_tmp.p, tb, hash_dev, S.d_hash2.as<uint64_t>(), count_dev, S.d_flag.as<int32_t>(), (size_t)n, 0, 64, s));
+    if (int rc = S.d_uniq.ensure(8 * n)) return rc;
+    if (int rc = S.d_cnt.ensure(4 * n)) return rc;
+    if (int rc = S.d_n.ensure(8)) return rc;
+    DG_HIP(rocprim::reduce_by_key(nullptr, tb, S.d_hash2.as<uint64_t>(), S.d_flag.as<int32_t>(), (size_t)n, S.d_uniq.as<uint64_t>(),
+                                  S.d_cnt.as<int32_t>(), S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(), rocprim::equal_to<uint64_t>(), s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::reduce_by_key(S.d_tmp.p, tb, S.d_hash2.as<uint64_t>(), S.d_flag.as<int32_t>(), (size_t)n, S.d_uniq.as<uint64_t>(),
+                                  S.d_cnt.as<int32_t>(), S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(), rocprim::equal_to<uint64_t>(), s));
+    unsigned long long nd = 0;
+    DG_HIP(hipMemcpyAsync(&nd, S.d_n.p, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipStreamSynchronize(s));
+    if ((int64_t)nd > cap) { set_error("merge: %llu distinct exceed capacity %lld", nd, (long long)cap); return DG_ERR_ARG; }
+    DG_HIP(hipMemcpyAsync(out_hash_dev, S.d_uniq.p, 8 * (size_t)nd, hipMemcpyDeviceToDevice, s));
+    DG_HIP(hipMemcpyAsync(out_count_dev, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToDevice, s));
+    DG_HIP(hipStreamSynchronize(s));
+    *n_out = (int64_t)nd;
+    return DG_OK;
+}

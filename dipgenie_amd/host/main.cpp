@@ -1,0 +1,106 @@
+// DipGenie drop-in CLI for the diploid hot path on MI355X.
+//
+// Same command line as the reference (/root/reference/src/main.cpp:39-111): -t -p -R -g -r -o -k -w
+// -T -d are honoured; -a -q -N -m -P -H -l -c are accepted and ignored exactly as the reference's DP
+// path ignores them. The two device loops go through libdipgenie_hip.so; there is no
+// CPU fallback: without a usable gfx950 device the program exits with an error.
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "pipeline.hpp"
+
+static int b_sketch_reads(void *c, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **cnt, int64_t *nd) {
+    return dg_sketch_reads((dg_ctx *)c, b, off, n, k, w, h, cnt, nd);
+}
+static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) {
+    return dg_sketch_haplotype((dg_ctx *)c, s, len, k, w, h, p, n);
+}
+static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
+
+static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
+    fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");
+    fprintf(fp, "Options:\n");
+    fprintf(fp, "    -a bool      DP approximation mode\n");
+    fprintf(fp, "    -k INT       K-mer size [%d]\n", o.k);
+    fprintf(fp, "    -w INT       Minimizer window size [%d]\n", o.w);
+    fprintf(fp, "    -R INT       Recombination limit [%d]\n", o.R);
+    fprintf(fp, "    -p INT       Ploidy (default diploid i.e -p2, use -p1 for haploid) [%d]\n", o.ploidy);
+    fprintf(fp, "    -T FLOAT     Threshold for minimizer filtering [%.3f]\n", o.threshold);
+    fprintf(fp, "    -t INT       Threads [%d]\n", o.threads);
+    fprintf(fp, "    -g INT       GFA file [%s]\n", o.gfa_file.c_str());
+    fprintf(fp, "    -r INT       Read [%s]\n", o.reads_file.c_str());
+    fprintf(fp, "    -o INT       Output haplotype [%s]\n", o.hap_file.c_str());
+    fprintf(fp, "    -d bool      Debug mode [%d]\n", (int)o.debug);
+    fprintf(fp, "    -G INT       (MI355X build) HIP device ordinal [0]\n");
+}
+
+int main(int argc, char **argv) {
+    dg::Pipeline p;
+    int device = 0, help = 0;
+    std::string json;
+    for (int i = 1; i < argc; ++i)
+        if (!strcmp(argv[i], "--version")) { fprintf(stderr, "PHI version: 1.0 (dipgenie-mi355x)\n"); return 0; }
+    int c;
+    // reference option string: "x:p:d:c:l:s:m:R:P:a:q:T:H:N:m:h:k:w:t:g:r:o:DSc" (main.cpp:39); -G -J -D are ours
+    while ((c = getopt(argc, argv, "x:p:d:c:l:s:m:R:P:a:q:T:H:N:h:k:w:t:g:r:o:G:J:D:")) >= 0) {
+        switch (c) {
+        case 'w': p.opt.w = atoi(optarg); break;
+        case 'k': p.opt.k = atoi(optarg); break;
+        case 'p': p.opt.ploidy = atoi(optarg); break;
+        case 't': p.opt.threads = atoi(optarg); break;
+        case 'g': p.opt.gfa_file = optarg; break;
+        case 'R': p.opt.R = atoi(optarg); break;
+        case 'T': p.opt.threshold = (float)atof(optarg); break;
+        case 'r': p.opt.reads_file = optarg; break;
+        case 'o': p.opt.hap_file = optarg; break;
+        case 'd': p.opt.debug = atoi(optarg); break;
+        case 'h': help = 1; break;
+        case 'G': device = atoi(optarg); break;
+        case 'J': json = optarg; break;
+        case 'D': p.opt.dump_prefix = optarg; break;
+        default: break;   // parsed-but-unused on this path
+        }
+    }
+    if (argc < 2 || p.opt.gfa_file.empty() || p.opt.reads_file.empty() || p.opt.hap_file.empty() || help) {
+        usage(stderr, p.opt);
+        return 1;
+    }
+    dg_ctx *ctx = dg_create(device);
+    if (!ctx) { fprintf(stderr, "[E::main] %s\n", dg_last_error()); return 2; }
+    p.be.ctx = ctx;
+    p.be.sketch_reads = b_sketch_reads;
+    p.be.sketch_haplotype = b_sketch_hap;
+    p.be.dp_solve_diploid = b_dp;
+    p.be.free_buf = dg_free;
+    p.be.last_error = dg_last_error;
+    double t0 = dg::now_s();
+    std::string err;
+    int rc = p.run(err);
+    if (rc != 0) { fprintf(stderr, "[E::main] %s\n", err.c_str()); dg_destroy(ctx); return 1; }
+    dg_dp_timing tm;
+    if (p.opt.ploidy == 2 && dg_dp_get_timing(ctx, &tm) == DG_OK)
+        fprintf(stderr, "[dg::dp] delta %.3f ms, forward %.3f ms (%lld launches), traceback %.3f ms; %.3f G cells, %.3f G relaxations\n",
+                tm.delta_ms, tm.forward_ms, (long long)tm.n_forward_launches, tm.traceback_ms, p.sum.cells / 1e9, p.sum.relaxations / 1e9);
+    if (!json.empty()) {
+        FILE *f = fopen(json.c_str(), "w");
+        if (f) {
+            fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "
+                       "\"spectrum\": %lld, \"n_levels\": %lld, \"n_vertices\": %lld, \"cells\": %llu, \"relaxations\": %llu, "
+                       "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"stages\": {",
+                    p.sum.dp_value, p.sum.s_het, p.sum.r1, p.sum.r2, p.sum.obj, (long long)p.sum.len1, (long long)p.sum.len2,
+                    (long long)p.sum.spectrum, (long long)p.sum.n_levels, (long long)p.sum.n_vertices,
+                    (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll);
+            for (size_t i = 0; i < p.sum.stage_s.size(); ++i)
+                fprintf(f, "%s\"%s\": %.6f", i ? ", " : "", p.sum.stage_s[i].first.c_str(), p.sum.stage_s[i].second);
+            fprintf(f, "}}\n");
+            fclose(f);
+        }
+    }
+    fprintf(stderr, "[M::main] Real time: %.3f sec\n", dg::now_s() - t0);
+    dg_destroy(ctx);
+    return 0;
+}
