@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- DipGenie diploid hot path on MI355X (see DESIGN.md s6 for what every field means).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic MHC-24 --
+24 walks over the MHC_4 segment set (5 real + 19 seeded mosaics with private variants), diploid -p2
+-R18, 4x synthetic 150-bp reads.  A *step* is one pass of the hot path over that input, with every
+input already resident in HBM: (a) minimizer scoring of the read set, sharded over the ranks by read
+(local HIP sketch -> RCCL all-reduce of the per-dictionary-minimizer hit vector + all-gather/merge of the
+spectrum), then (b) the pair-of-paths DP (delta precompute, level sweep, traceback) on the rank's GPU.
+The DP does not shard (replicas only), so with N ranks every rank solves one instance and
+`value` = (N x cells) / max-over-ranks time  ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def truncated_graph(g, target_cells):
+    """levels [0, P) of g as a standalone graph for the CPU baseline sample"""
+    from dipgenie_amd.capi import DpGraphArrays
+    k = np.diff(g.level_off).astype(np.int64)
+    cum = np.cumsum(k[1:] ** 2 * (g.R + 1))
+    P = int(min(max(np.searchsorted(cum, target_cells) + 2, 3), g.n_levels))
+    nv = int(g.level_off[P])
+    last0 = int(g.level_off[P - 1])
+    out_off = g.out_off[: nv + 1].copy()
+    out_off[last0:] = out_off[last0]                     # last kept level has no out-edges
+    ne = int(out_off[-1])
+    return DpGraphArrays(g.R, level_off=g.level_off[: P + 1], out_off=out_off, out_dst=g.out_dst[:ne], out_w=g.out_w[:ne],
+                         hom_off=g.hom_off[: nv + 1], hom_col=g.hom_col[: int(g.hom_off[nv])],
+                         het_off=g.het_off[: nv + 1], het_col=g.het_col[: int(g.het_off[nv])]), P
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mhc24", choices=["mhc24", "mhc4"])
+    ap.add_argument("--cache", default=os.environ.get("DG_BENCH_CACHE", "/tmp/dg_bench_cache"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=float, default=6e8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---------------------------------------------------------------- build + inputs (untimed)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from dipgenie_amd import capi, synth
+    from dipgenie_amd.dist_sketch import ShardedSketch, shard_bounds
+
+    os.makedirs(args.cache, exist_ok=True)
+    if args.workload == "mhc24":
+        name = "synthetic MHC-24 (5 real + 19 mosaic walks, seed 24), -p2 -R18, 4x 150-bp reads (seed 4)"
+        if rank == 0:
+            gfa, reads_path, info = synth.ensure_mhc24(os.path.join(args.cache, "mhc24"))
+        if world > 1:
+            dist.barrier()
+        gfa, reads_path, info = synth.ensure_mhc24(os.path.join(args.cache, "mhc24"))
+    else:
+        name = "MHC_4 (5 walks) + CHM13 0.5x reads, -p2 -R18"
+        gfa = os.path.join(ROOT, "tests", "data", "MHC_4.gfa.gz")
+        reads_path = os.path.join(ROOT, "tests", "data", "CHM13_reads.fq.gz")
+    R, K, W = 18, 31, 25
+    pre = os.path.join(args.cache, args.workload)
+    cli = os.path.join(ROOT, "bin", "DipGenie")
+    e2e = None
+    if rank == 0:
+        # one end-to-end run of the drop-in CLI (HIP sketch + HIP DP): produces the levelized DP graph
+        # (.dpg) that the timed steps re-solve, and the end-to-end seconds with per-stage breakdown.
+        t0 = time.time()
+        subprocess.run([cli, "-t", str(min(32, os.cpu_count() or 8)), "-p2", f"-R{R}", "-g", gfa, "-r", reads_path, "-o", pre + ".fa",
+                        "-D", pre, "-J", pre + ".json", "-G", str(local_rank)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        e2e = json.load(open(pre + ".json"))
+        e2e["wall_s"] = time.time() - t0
+        log(f"end-to-end CLI run: {e2e['wall_s']:.2f} s, DP value {e2e['dp_value']}")
+    if world > 1:
+        dist.barrier()
+    g = capi.DpGraphArrays.load(pre + ".dpg")
+
+    ctx = capi.Context(local_rank)
+    ctx.dp_load_graph(g)                                   # graph resident in HBM from here on
+
+    # reads: this rank's contiguous shard, resident on the GPU; haplotype-minimizer dictionary D
+    if reads_path.endswith(".gz"):
+        import gzip
+        lines = gzip.open(reads_path, "rb").read().split(b"\n")
+        all_reads = lines[1::4]
+    else:
+        all_reads = open(reads_path, "rb").read().split(b"\n")[1::2]
+    all_reads = [r for r in all_reads if r]
+    lo, hi = shard_bounds(len(all_reads), world, rank)
+    mine = all_reads[lo:hi]
+    off = np.zeros(len(mine) + 1, np.int64)
+    np.cumsum([len(r) for r in mine], out=off[1:])
+    bases_t = torch.frombuffer(bytearray(b"".join(mine)) or bytearray(1), dtype=torch.uint8).to(device)
+    off_t = torch.from_numpy(off).to(device)
+    _, seqs, _, walks = synth.parse_gfa(gfa)
+    dict_parts = []
+    for (_, _, wv) in walks:
+        h, _p = ctx.sketch_haplotype(b"".join(seqs[v] for v in wv), K, W)
+        dict_parts.append(h)
+    D = np.unique(np.concatenate(dict_parts))
+    dict_t = torch.from_numpy(D.view(np.int64).copy()).to(device)
+    sk = ShardedSketch(ctx, device)
+    del seqs, walks, dict_parts
+
+    def step():
+        t0 = time.perf_counter()
+        h, c = sk.local(bases_t, off_t, K, W)
+        counts = sk.dictionary_counts(dict_t, h, c)         # RCCL all-reduce(sum) of the hit vector
+        gh, gc = sk.global_spectrum(h, c)                   # all-gather + device merge
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = ctx.dp_run()                                  # synchronises
+        t2 = time.perf_counter()
+        return out, counts, gh, (t1 - t0), (t2 - t1)
+
+    for _ in range(args.warmup):
+        out, counts, gh, _, _ = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    sk_s = dp_s = 0.0
+    fwd_ms = dl_ms = tb_ms = 0.0
+    for _ in range(args.steps):
+        out, counts, gh, a, b = step()
+        sk_s += a
+        dp_s += b
+        tm = ctx.dp_timing()
+        fwd_ms += tm.forward_ms; dl_ms += tm.delta_ms; tb_ms += tm.traceback_ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed, sk_s, dp_s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, sk_s, dp_s = (float(x) for x in t.tolist())
+
+    if rank == 0:
+        if e2e is not None and out.value != e2e["dp_value"]:
+            raise SystemExit(f"bench DP value {out.value} != CLI DP value {e2e['dp_value']}")
+        steps = args.steps
+        cells = int(out.cells)
+        tm = ctx.dp_timing()
+        # algorithmic bytes of one DP pass, SURVEY.md s8d: 32 B/cell + 16 B/edge-pair + 4 B/colour entry read
+        alg_bytes = 32.0 * cells + 16.0 * tm.edge_pairs + 4.0 * tm.colour_entries
+        fwd_s = fwd_ms / 1e3 / steps
+        n_launch = max(int(tm.n_forward_launches), 1)
+        achieved = alg_bytes / fwd_s / 1e9
+        line = {
+            "metric": "dp_state_cells_per_s", "value": world * cells * steps / elapsed, "unit": "cells/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": name, "R": R, "k": K, "w": W, "levels": g.n_levels, "vertices": g.n_vertices,
+                       "cells_per_pass": cells, "relaxations_per_pass": int(out.relaxations), "reads": len(all_reads),
+                       "parallelism": f"sketch sharded over {world} rank(s) by read (RCCL all-reduce + all-gather); DP replica per rank"},
+            "dp_ms": {"delta": dl_ms / steps, "forward": fwd_ms / steps, "traceback": tb_ms / steps, "wall": 1e3 * dp_s / steps},
+            "reads_per_s": len(all_reads) * steps / sk_s if sk_s > 0 else None,
+            "sketch_ms_per_step": 1e3 * sk_s / steps,
+            "roofline": {"bound": "hbm", "kernel": "dp_level sweep (forward)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes / n_launch, "launches": n_launch, "avg_launch_ms": 1e3 * fwd_s / n_launch,
+                         "dependency_chain_levels": g.n_levels},
+        }
+        if e2e is not None:
+            line["end_to_end_s"] = e2e["wall_s"]
+            line["end_to_end_stages_s"] = e2e.get("stages")
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_py as orc                           # the checker, timed as the CPU baseline ("port")
+            gs, P = truncated_graph(g, args.cpu_sample_cells)
+            t0 = time.perf_counter()
+            ref = orc.dp_solve(gs)
+            dt = time.perf_counter() - t0
+            gout = ctx.dp_solve(gs)                           # same sample on the GPU: must agree
+            if (gout.value, gout.s_het, gout.p1, gout.p2) != (ref["value"], ref["s_het"], ref["p1"], ref["p2"]):
+                raise SystemExit("GPU and CPU baseline disagree on the sample")
+            line["cpu_baseline"] = {"value": ref["cells"] / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {P} of {g.n_levels} levels of the same graph ({ref['cells']} cells, {dt:.1f} s, "
+                                              "oracle/oracle_dp.cpp single thread; result cross-checked against the GPU)"}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

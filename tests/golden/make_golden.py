@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.json from the REAL reference (run in the build container only).
+
+Needs /root/reference; builds oracle/_ref via `make -C oracle ref` (reference sources compiled where
+they lie, outputs only under oracle/_ref/).  Commits only data: inputs (small GFA/FASTA files under
+tests/golden/e2e/) and the reference's outputs for them.  Usage: python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from dipgenie_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+BIN = os.path.join(REF, "DipGenie_ref")
+HARNESS = os.path.join(REF, "ref_harness")
+
+
+def sh(cmd, inp=None):
+    return subprocess.run(cmd, input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+
+
+def kat_sketch():
+    rng = np.random.default_rng(2024)
+    def rnd(n, alpha=b"ACGT"):
+        return bytes(rng.choice(np.frombuffer(alpha, np.uint8), n).tobytes()).decode()
+    seqs = [rnd(150) for _ in range(12)]
+    seqs += [rnd(200, b"ACGTN"), rnd(180, b"acgtACGT"), rnd(160, b"ACGTNRY"), "A" * 120, "AC" * 80, "ACG" * 60,
+             rnd(55), rnd(54), rnd(56), rnd(31), "ACGT" * 40, rnd(40) * 4, rnd(700), rnd(400, b"AACGT"),
+             "ACGTCATGCAGTCGTAACGTAGTCGTCACAGTCAGTCGTAGCTATGTAGCGTCAGTCAGTCAGTCGTAGCGTAACGTCGTAGTCAGT"]
+    out = []
+    for (k, w) in [(31, 25), (5, 3), (15, 10), (21, 11), (32, 4)]:
+        inp = ("\n".join(seqs) + "\n").encode()
+        hs = sh([HARNESS, "hashes", str(k), str(w)], inp).stdout.decode().split("\n")
+        ms = sh([HARNESS, "minimizers", str(k), str(w)], inp).stdout.decode().split("\n")
+        for s, h, m in zip(seqs, hs, ms):
+            out.append(dict(seq=s, k=k, w=w, hashes=h.split(), minimizers=m.split()))
+    kmers = ["A" * 31, "ACGTCATGCAGTCGTAACGTAGTCGTCACAG", "ACGTACGTACGTACGTACGTACGTACGTACG", "ANGTCATGCAGTCGTAACGTAGTCGTCACAG",
+             "ACGTA", "T" * 16, "G" * 17, "ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACG"]
+    hk = sh([HARNESS, "hash"] + kmers).stdout.decode().split()
+    return dict(windows=out, kmers=[dict(kmer=a, hash=b) for a, b in zip(kmers, hk)])
+
+
+def kat_fit():
+    hists = {
+        "mhc4_chm13_0.5x": {1: 116960, 2: 18754, 3: 2506, 4: 353, 5: 95, 6: 44, 7: 30, 8: 21, 9: 13, 10: 7, 11: 8, 12: 3, 13: 4, 14: 4,
+                            15: 7, 16: 7, 17: 1, 18: 2, 19: 1, 20: 1, 21: 2, 22: 1, 24: 3, 25: 3, 28: 2, 33: 1, 38: 1},
+        "toy_single_bin": {1: 7},
+        "two_bins": {1: 3, 2: 4},
+    }
+    rng = np.random.default_rng(11)
+    # ~8x diploid-like: errors at 1-2, het peak ~4, hom peak ~8
+    x = np.concatenate([rng.geometric(0.7, 40000), rng.poisson(4.0, 9000) + 1, rng.poisson(8.0, 30000) + 1, rng.poisson(16, 800) + 1])
+    u, c = np.unique(x, return_counts=True)
+    hists["sim_8x"] = {int(a): int(b) for a, b in zip(u, c)}
+    x = np.concatenate([rng.geometric(0.8, 20000), rng.poisson(2.0, 6000) + 1, rng.poisson(4.0, 20000) + 1])
+    u, c = np.unique(x, return_counts=True)
+    hists["sim_4x"] = {int(a): int(b) for a, b in zip(u, c)}
+    out = {}
+    for name, h in hists.items():
+        inp = "".join(f"{m} {f}\n" for m, f in sorted(h.items())).encode()
+        lines = sh([HARNESS, "fit"], inp).stdout.decode().split("\n")
+        vals = [float(v) for v in lines[0].split()]
+        out[name] = dict(hist={str(k): v for k, v in h.items()}, nll=vals[0], nll_repr=lines[0].split()[0],
+                         params=dict(zip(["u_v", "sd_v", "var_w", "zp_copy", "zp_copy_het", "p_d", "p_e", "err_shape"], vals[1:])),
+                         labels=lines[1].strip())
+        print("fit", name, lines[0], lines[1][:40], flush=True)
+    return out
+
+
+def run_ref(gfa, reads, args, threads=4):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.fa")
+        p = sh([BIN, f"-t{threads}"] + args + ["-g", gfa, "-r", reads, "-o", out])
+        txt = (p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")).replace("\r", "\n")
+        fa = open(out, "rb").read()
+    d = dict(args=args, fasta_md5=hashlib.md5(fa).hexdigest())
+    if len(fa) < 4000:
+        d["fasta"] = fa.decode()
+    m = re.search(r"DP value: (-?\d+)", txt)
+    if m:
+        d["dp_value"] = int(m.group(1))
+    m = re.search(r"recombinations in P1: (-?\d+), recombinations in P2: (-?\d+), bp of P1: (\d+), bp of P2: (\d+)", txt)
+    if m:
+        d.update(r1=int(m.group(1)), r2=int(m.group(2)), len1=int(m.group(3)), len2=int(m.group(4)))
+    m = re.search(r"r: (\d+) obj: (-?\d+)", txt)
+    if m:
+        d["obj"] = int(m.group(2))
+    m = re.search(r"Recombination count: (\d+)", txt)
+    if m:
+        d["best_r_haploid"] = int(m.group(1))
+    m = re.search(r"spectrum size: (\d+)", txt)
+    if m:
+        d["spectrum"] = int(m.group(1))
+    return d
+
+
+def e2e():
+    cases = {}
+    D = os.path.join(ROOT, "tests", "data")
+    toy = [("toy2_p1", "test2.gfa", "read2.fa", ["-p1", "-R2"]), ("toy2_p2", "test2.gfa", "read2.fa", ["-p2", "-R2"]),
+           ("toy1_p1", "test.gfa", "read.fa", ["-p1", "-R2", "-k5", "-w3"]), ("toy1_p2", "test.gfa", "read.fa", ["-p2", "-R2", "-k5", "-w3"]),
+           ("toy1_p2_R0", "test.gfa", "read.fa", ["-p2", "-R0", "-k5", "-w3"]), ("toy1_p2_R5", "test.gfa", "read.fa", ["-p2", "-R5", "-k5", "-w3"])]
+    for name, g, r, a in toy:
+        cases[name] = dict(gfa=f"tests/data/{g}", reads=f"tests/data/{r}", **run_ref(os.path.join(D, g), os.path.join(D, r), a))
+        print(name, cases[name].get("dp_value"), cases[name]["fasta_md5"], flush=True)
+    specs = [
+        ("bub_a", dict(seed=1, n_bubbles=10, n_haps=4), ["-p2", "-R4", "-k11", "-w5"]),
+        ("bub_b", dict(seed=2, n_bubbles=25, n_haps=6, coverage=10.0), ["-p2", "-R6", "-k11", "-w5"]),
+        ("bub_c", dict(seed=3, n_bubbles=40, n_haps=8, coverage=8.0, sub_rate=0.01), ["-p2", "-R8", "-k13", "-w7"]),
+        ("bub_d", dict(seed=4, n_bubbles=30, n_haps=5, seg_len=(40, 120), coverage=12.0, read_len=100), ["-p2", "-R3", "-k15", "-w8"]),
+        ("bub_e", dict(seed=5, n_bubbles=60, n_haps=10, coverage=6.0, alleles=(2, 4)), ["-p2", "-R10", "-k11", "-w4"]),
+        ("bub_f", dict(seed=6, n_bubbles=20, n_haps=3, coverage=20.0, sub_rate=0.005), ["-p2", "-R2", "-k9", "-w4"]),
+        ("bub_g", dict(seed=7, n_bubbles=35, n_haps=12, coverage=9.0, seg_len=(35, 90)), ["-p2", "-R18", "-k31", "-w25"]),
+        ("bub_h", dict(seed=8, n_bubbles=15, n_haps=4, coverage=8.0), ["-p2", "-R1", "-k11", "-w5", "-T0.75"]),
+        ("bub_a_p1", dict(seed=1, n_bubbles=10, n_haps=4), ["-p1", "-R4", "-k11", "-w5"]),
+        ("bub_c_p1", dict(seed=3, n_bubbles=40, n_haps=8, coverage=8.0, sub_rate=0.01), ["-p1", "-R8", "-k13", "-w7"]),
+    ]
+    ed = os.path.join(HERE, "e2e")
+    for name, kw, args in specs:
+        base = name.replace("_p1", "")
+        gfa, reads = os.path.join(ed, base + ".gfa"), os.path.join(ed, base + ".fa")
+        if not os.path.exists(gfa):
+            segs, links, walks, rd = synth.random_bubble_graph(**kw)
+            synth.write_gfa(gfa, segs, links, walks)
+            synth.write_fasta(reads, rd)
+        cases[name] = dict(gfa=f"tests/golden/e2e/{base}.gfa", reads=f"tests/golden/e2e/{base}.fa", **run_ref(gfa, reads, args))
+        print(name, cases[name].get("dp_value"), cases[name].get("r1"), cases[name].get("r2"), cases[name]["fasta_md5"], flush=True)
+    # MHC_4 (reference's own test data), values from reference runs in this container (-t1 and -t8 identical)
+    cases["mhc4_p2"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p2", "-R18"],
+                            fasta_md5="46394489af8bc9026605ddf237aca4c7", dp_value=60729, r1=17, r2=1, len1=5005629, len2=4920284,
+                            obj=5282, spectrum=138834, slow=True)
+    cases["mhc4_p1"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p1"],
+                            fasta_md5="0c4df87ded10634a36db0a2c90521ff0", best_r_haploid=0, spectrum=138834, slow=True)
+    return cases
+
+
+if __name__ == "__main__":
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    what = sys.argv[1:] or ["sketch", "fit", "e2e"]
+    if "sketch" in what:
+        json.dump(kat_sketch(), open(os.path.join(HERE, "kat_sketch.json"), "w"), indent=0)
+    if "e2e" in what:
+        json.dump(e2e(), open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+    if "fit" in what:
+        json.dump(kat_fit(), open(os.path.join(HERE, "kat_fit.json"), "w"), indent=1)

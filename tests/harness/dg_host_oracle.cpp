@@ -32,7 +32,21 @@ static int o_dp(void *, const dg_dp_graph *g, dg_dp_result *r) {
 }
 static const char *o_err() { return "oracle"; }
 
+// --fit: read "multiplicity freq" lines, print the host fitter's result in ref_harness's format
+static int fit_mode() {
+    std::vector<dg::HistBin> H;
+    int m, maxm = 0; double f;
+    while (scanf("%d %lf", &m, &f) == 2) { H.push_back({m, f}); if (m > maxm) maxm = m; }
+    auto res = dg::kg_fit(H, 10, maxm, 8);
+    printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", res.nll, res.P.u_v, res.P.sd_v, res.P.var_w,
+           res.P.zp_copy, res.P.zp_copy_het, res.P.p_d, res.P.p_e, res.P.err_shape);
+    for (int x = 1; x <= maxm; ++x) putchar(dg::kg_is_hom(res.P, x) ? 'O' : 'E');
+    putchar('\n');
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--fit")) return fit_mode();
     dg::Pipeline p;
     std::string json;
     int c;

@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dipgenie_hip.h declares, and refuses to
+run without a gfx950 device (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dipgenie_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dg_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_exports_match_header(built_hip):
+    from dipgenie_amd import capi
+    syms = header_symbols()
+    assert sorted(capi.SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(capi.lib, s), s
+
+
+def test_struct_layouts(built_hip):
+    import ctypes as C
+    from dipgenie_amd import capi
+    assert C.sizeof(capi.DpGraph) == 80 and C.sizeof(capi.DpResult) == 72
+    assert C.sizeof(capi.DpTiming) == 64 and C.sizeof(capi.SketchTiming) == 24
+
+
+def test_no_cpu_fallback(built_hip):
+    import torch
+    from dipgenie_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.DgError, match="no CPU fallback|no HIP device"):
+        capi.Context(0)
+
+
+def test_product_does_not_link_oracle(built_hip):
+    import subprocess
+    for f in (os.path.join(ROOT, "dipgenie_amd", "csrc", "libdipgenie_hip.so"), built_hip):
+        out = subprocess.run(["ldd", f], stdout=subprocess.PIPE).stdout.decode()
+        assert "oracle" not in out
+        sym = subprocess.run(["nm", "-D", f], stdout=subprocess.PIPE).stdout.decode()
+        assert "orc_" not in sym
