@@ -6,8 +6,8 @@
 //     in(u2) x in(v2); in-edges are stored sorted by source position, so a strict '>' scan
 //     reproduces the reference's take-if total order (value desc, pred_i asc, pred_j asc, :657-659)
 //     without locks or atomics, and no destination is ever "reset" (:565-576 disappears);
-//   * rolling value state is 4 B/cell ([i][j][r], r fastest -> lanes of a wave read consecutive
-//     addresses); s_het / edge chains are not carried (reference cell = 40 B).  Instead every cell
+//   * rolling value state is 4 B/cell, layout [i][r][j] (j fastest: lanes of a wave run along the
+//     destination columns and read (near-)consecutive addresses); s_het / edge chains are not carried (reference cell = 40 B).  Instead every cell
 //     streams one 4-byte back-pointer (pred_i | pred_j<<15 | wu<<30 | wv<<31) to HBM and a
 //     traceback kernel walks the lattice from the sink, emitting the weighted-edge lists (:757-764,
 //     :673-692) and re-deriving s_het from the colour lists of the L winning edge pairs;
@@ -15,6 +15,7 @@
 //     transition that touches a colour, the T x T matrix delta[e_u][e_v] (uint16), T = #in-edges of
 //     the destination level; colourless transitions (73 % on MHC_4) skip the lookup.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "dg_internal.hpp"
@@ -32,6 +33,10 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t T;                                          // in-edges into the destination level
     int64_t delta_off;                                  // offset of the T*T uint16 matrix, -1 if all zero
     int64_t bp_off;                                     // offset of this level's cells in the bp lattice
+    int32_t grp_first, ngroups;                         // column groups (runs of <=64 in-edges covering whole columns)
+    int32_t dead_first, ndead;                          // destination columns with no in-edge
+    int64_t slot_first;                                 // first entry of this level in the 64-wide slot table
+    int32_t fast_ok, pad_;                              // 1: every in-degree <= 64 and sizes fit the fast kernel
 };
 
 struct TraceOut {
@@ -41,12 +46,18 @@ struct TraceOut {
 struct DpState {
     int32_t nV = 0, L = 0, R = 0, RP = 0, cap = 0;
     bool loaded = false;
-    int64_t want_digest = 0, use_graph = 1, max_blocks = 2048;
+    int64_t want_digest = 0, use_fast = 1, use_team = 0, team_grid = 256, max_blocks = 1024, team_fallbacks = 0;
+    int last_team_size = 0;
+    bool all_fast = false;
+    int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 1, chip_waves = 8192;
+    struct Segment { int begin, end; bool team; };
+    std::vector<Segment> schedule;
+    size_t state_alloc_bytes = 0;
     std::vector<LevelDesc> descs;
     uint64_t cells = 0, relaxations = 0, edge_pairs = 0, colour_entries = 0;
-    int64_t total_cells = 0, max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0;
+    int64_t total_cells = 0, max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans;
+    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots;
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -101,6 +112,8 @@ __device__ __forceinline__ int score_symd(const ColourCsr &c, int u1, int v1, in
 // One block handles DELTA_PER_BLOCK consecutive entries of one transition's T*T matrix.
 // ---------------------------------------------------------------------------------------------
 constexpr int DELTA_PER_BLOCK = 256 * 8;
+constexpr int TEAM_CTL_SLOTS = 64;                      // control blocks recycled by successive team launches
+constexpr int DELTA_PAD = 8;                            // delta[0..8) stays zero: the colourless transitions' slot
 
 __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restrict__ descs,
                                                        const int32_t *__restrict__ dtrans,      // coloured transition -> level
@@ -134,52 +147,415 @@ __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// level sweep, whole-chip form: one launch per transition, grid-stride over destination cells
+// level sweep, edge-pair form (the production kernel).  State layout [i][r][j] (j fastest).
+//
+// The work of one transition is the T x T grid of in-edge pairs (e_u, e_v) -- exactly the index
+// space of the delta matrix.  One wave owns one task = (destination row i2, column group g): a group
+// is a run of <= 64 consecutive in-edges e_v that covers whole destination columns (host-built), so
+// lane <-> e_v and every destination cell's candidates sit in adjacent lanes.  The wave walks the
+// row's in-edges e_u (wave-uniform), and per step every lane does one delta load (coalesced along
+// e_v) and RC value loads (coalesced along the source column j) -- no per-lane inner loop, so a
+// vertex with in-degree 24 costs 24 steps instead of 24 x 24.  Each lane keeps, per recombination
+// count, the best candidate as the pair (value, ord) with ord = (~i, ~j, wu, wv) packed so that a
+// plain lexicographic max IS the reference's take-if order (value desc, pred_i asc, pred_j asc,
+// approximator.cpp:657-659).  A log-step segmented max over lanes of equal destination column
+// finishes the cell; the segment head stores the value and the back-pointer.
 // ---------------------------------------------------------------------------------------------
-template <bool DIGEST>
-__global__ __launch_bounds__(256) void dp_level_kernel(const LevelDesc *__restrict__ descs, int lvl, int RP,
-                                                       const uint32_t *__restrict__ in_off,
-                                                       const uint32_t *__restrict__ in_edge,
-                                                       const uint16_t *__restrict__ delta,
-                                                       const int32_t *__restrict__ cur, int32_t *__restrict__ nxt,
-                                                       uint32_t *__restrict__ bp, unsigned long long *digest) {
-    const LevelDesc d = descs[lvl];
-    const int64_t ncell = (int64_t)d.k2 * d.k2 * RP;
+struct SweepArgs {
+    const LevelDesc *descs;
+    const uint32_t *in_off, *in_edge, *grp_begin;
+    const int32_t *in_dst, *dead_cols;
+    const uint16_t *delta;
+    int32_t *buf0, *buf1;
+    uint32_t *bp;
+    unsigned long long *digest;
+    int RP;
+};
+
+__device__ __forceinline__ uint32_t ord_word(int i, int j, int wu, int wv) {
+    return ((uint32_t)(0x7FFF - i) << 17) | ((uint32_t)(0x7FFF - j) << 2) | ((uint32_t)wu << 1) | (uint32_t)wv;
+}
+__device__ __forceinline__ uint32_t bp_from_ord(uint32_t o) {
+    const uint32_t i = 0x7FFFu - (o >> 17), j = 0x7FFFu - ((o >> 2) & 0x7FFFu);
+    return i | (j << 15) | (((o >> 1) & 1u) << 30) | ((o & 1u) << 31);
+}
+
+template <int RC, bool DIGEST>
+__device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, int wave_id, int n_waves) {
+    const LevelDesc d = A.descs[lvl];
+    const int RP = A.RP;
+    const int32_t *__restrict__ cur = ((lvl - 1) & 1) ? A.buf1 : A.buf0;
+    int32_t *__restrict__ nxt = (lvl & 1) ? A.buf1 : A.buf0;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (RP + RC - 1) / RC;
+    const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
     const bool has_delta = d.delta_off >= 0;
-    const uint16_t *dm = delta + (has_delta ? d.delta_off : 0);
-    const int64_t rowstride = (int64_t)d.k * RP;
+    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const int dT = has_delta ? d.T : 0, dmask = has_delta ? -1 : 0;
+    const uint32_t *gb = A.grp_begin + d.grp_first;
     unsigned long long dsum = 0;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < ncell; t += (int64_t)gridDim.x * 256) {
-        const int p = (int)(t / RP), r2 = (int)(t - (int64_t)p * RP);
-        const int i2 = p / d.k2, j2 = p - i2 * d.k2;
-        const uint32_t eu0 = in_off[d.b0 + i2], eu1 = in_off[d.b0 + i2 + 1];
-        const uint32_t ev0 = in_off[d.b0 + j2], ev1 = in_off[d.b0 + j2 + 1];
-        int best = NEG_INF;
-        uint32_t bpv = BP_NONE;
-        for (uint32_t eu = eu0; eu < eu1; ++eu) {
-            const uint32_t pu = in_edge[eu];
-            const int i = (int)(pu & 0x7FFFFFFFu), wu = (int)(pu >> 31);
-            const int32_t *row = cur + (int64_t)i * rowstride;
-            const uint16_t *drow = dm + (int64_t)(eu - d.in_base) * d.T;
-            for (uint32_t ev = ev0; ev < ev1; ++ev) {
-                const uint32_t pv = in_edge[ev];
-                const int j = (int)(pv & 0x7FFFFFFFu), wv = (int)(pv >> 31);
-                const int r = r2 - wu - wv;
-                if (r < 0) continue;                                   // r2 = r + wu + wv <= R  (:646-647)
-                const int val = row[(int64_t)j * RP + r];
-                if (val == NEG_INF) continue;                          // :633
-                const int cand = val + (has_delta ? (int)drow[ev - d.in_base] : 0);
-                if (cand > best) { best = cand; bpv = (uint32_t)i | ((uint32_t)j << 15) | ((uint32_t)wu << 30) | ((uint32_t)wv << 31); }
+    for (int64_t task = wave_id; task < ntask; task += n_waves) {
+        const int g = (int)(task % d.ngroups);
+        const int64_t rest = task / d.ngroups;
+        const int rc = (int)(rest % nchunk), i2 = (int)(rest / nchunk);
+        const int r0 = rc * RC;
+        const uint32_t gbeg = gb[g], gend = gb[g + 1];
+        const uint32_t eu0 = A.in_off[d.b0 + i2], eu1 = A.in_off[d.b0 + i2 + 1];
+        int bval[RC];
+        uint32_t bord[RC];
+#pragma unroll
+        for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+        int j2 = -1 - lane;                                             // inactive lanes: unique negative ids
+        // a group wider than 64 is one giant column (host guarantee): lanes accumulate over its chunks
+        for (uint32_t cb = gbeg; cb < gend; cb += 64) {
+            const uint32_t ev = cb + lane;
+            const bool act = ev < gend;
+            int j = 0, wv = 0;
+            if (act) {
+                const uint32_t pv = A.in_edge[ev];
+                j = (int)(pv & 0x7FFFFFFFu); wv = (int)(pv >> 31);
+                j2 = A.in_dst[ev] - d.b0;
+            }
+            const int dcol = (int)(ev - d.in_base) & dmask;
+            for (uint32_t eu = eu0; eu < eu1; ++eu) {
+                const uint32_t pu = A.in_edge[eu];
+                const int i = (int)(pu & 0x7FFFFFFFu), wu = (int)(pu >> 31);
+                if (act) {
+                    const int w = wu + wv;
+                    const int dl = (int)dm[(int64_t)(eu - d.in_base) * dT + dcol];
+                    const uint32_t ord = ord_word(i, j, wu, wv);
+                    // rows r = r2 - w; the buffers carry front/tail padding so r = -1, -2 (and r2 >= RP in a
+                    // ragged last chunk) are legal reads that the select discards: RC loads back to back
+                    const int32_t *base = cur + ((int64_t)i * RP + (r0 - w)) * d.k + j;
+                    int vals[RC];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) vals[q] = base[q * d.k];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) {
+                        const int cand = vals[q] + dl;
+                        const bool ok = (r0 + q < RP) & (r0 + q - w >= 0) & (vals[q] != NEG_INF);       // :633, :646-647
+                        const bool take = ok & ((cand > bval[q]) | ((cand == bval[q]) & (ord > bord[q])));   // :657-659
+                        bval[q] = take ? cand : bval[q];
+                        bord[q] = take ? ord : bord[q];
+                    }
+                }
             }
         }
-        nxt[t] = best;
-        bp[d.bp_off + t] = bpv;
-        if (DIGEST && best != NEG_INF) {
-            const unsigned long long idx = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
-            dsum += (unsigned long long)(uint32_t)(best + 1) * (idx + 1);
+        // segmented max over lanes with equal destination column (lanes of a column are adjacent)
+        const int span = (int)min(gend - gbeg, 64u);
+        for (int s = 1; s < span; s <<= 1) {
+            const int oj2 = __shfl_down(j2, s);
+            const bool same = (lane + s < 64) & (oj2 == j2);
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const int ov = __shfl_down(bval[q], s);
+                const uint32_t oo = (uint32_t)__shfl_down((int)bord[q], s);
+                const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+                bval[q] = take ? ov : bval[q];
+                bord[q] = take ? oo : bord[q];
+            }
+        }
+        const int pj2 = __shfl_up(j2, 1);
+        const bool head = (j2 >= 0) & ((lane == 0) | (pj2 != j2));
+        if (head) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const int r2 = r0 + q;
+                if (r2 < RP) {
+                    const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                    nxt[idx] = bval[q];
+                    A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                    if (DIGEST && bval[q] != NEG_INF) {
+                        const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
+                        dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
+                    }
+                }
+            }
+        }
+        // destination columns without any in-edge are unreachable: nobody owns them, clear them here
+        if (g == 0 && d.ndead > 0) {
+            for (int t = lane; t < d.ndead * RC; t += 64) {
+                const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
+                if (r0 + q < RP) {
+                    const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
+                    nxt[idx] = NEG_INF;
+                    A.bp[d.bp_off + idx] = BP_NONE;
+                }
+            }
         }
     }
-    if (DIGEST && dsum) atomicAdd(&digest[lvl], dsum);
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast form of the same sweep.  A level's kernel starts with cold caches (kernel boundary), so its
+// duration is a chain of dependent memory round trips (~1 us each) -- the fast form cuts the chain to
+//   kernarg (LevelDesc by value)  ->  {row record, slot record}  ->  {delta, RC values}  ->  stores
+// * slot table: every column group is padded to exactly 64 records {j | wv<<15 | j2<<16, ev_local |
+//   steps<<28}, so a lane finds its in-edge without reading group offsets;
+// * row record {first in-edge, in-degree, in-edge 0, in-edge 1} serves 97 % of the rows in one load;
+//   heavier rows fetch their in-edge list once, one per lane, and broadcast with readlane;
+// * the row's in-edges are processed two per step so two sets of RC loads are in flight;
+// * the segmented max runs only ceil(log2(max column in-degree of the group)) steps.
+// Levels with a vertex of in-degree > 64 (or sizes beyond the 2-D grid) use the generic kernel above.
+// ---------------------------------------------------------------------------------------------
+struct FastArgs {
+    const uint4 *rowrec;
+    const uint2 *slots;
+    const uint32_t *in_edge;
+    const int32_t *dead_cols;
+    const uint16_t *delta;
+    int32_t *base0, *base1;                             // padded allocation starts of the two state buffers
+    uint32_t *bp;
+    unsigned long long *digest;
+    int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
+    uint32_t buf_bytes;                                 // size of one padded state buffer
+};
+
+template <int RC>
+__device__ __forceinline__ void relax_select(const int (&vals)[RC], int dl, uint32_t ord, int r0, int w, int RP,
+                                             int (&bval)[RC], uint32_t (&bord)[RC]) {
+#pragma unroll
+    for (int q = 0; q < RC; ++q) {
+        const int cand = vals[q] + dl;
+        const bool ok = (r0 + q < RP) & (r0 + q - w >= 0) & (vals[q] != NEG_INF);                   // :633, :646-647
+        const bool take = ok & ((cand > bval[q]) | ((cand == bval[q]) & (ord > bord[q])));           // :657-659
+        bval[q] = take ? cand : bval[q];
+        bord[q] = take ? ord : bord[q];
+    }
+}
+
+// One task of the fast form: destination row i2, column group g, recombination chunk starting at r0.
+// AUX is the cache policy of the state loads: 0 = plain (per-level launches: the kernel boundary makes
+// the previous level visible), 16 = sc1 (team kernel: served by the XCD's L2, bypassing the CU's L1).
+template <int RC, bool DIGEST, int AUX, bool PROF = false>
+__device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr) {
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+    if (PROF) q0 = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x & 63;
+    const int RP = A.RP;
+    const uint4 rr = A.rowrec[d.b0 + i2];                               // {eu0, du, pu0, pu1}
+    const uint2 sl = A.slots[d.slot_first + (int64_t)g * 64 + lane];
+    const bool act = sl.x != 0xFFFFFFFFu;
+    const int j = (int)(sl.x & 0x7FFFu), wv = (int)((sl.x >> 15) & 1u);
+    const int j2 = act ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
+    const int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
+    const bool has_delta = d.delta_off >= 0;
+    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const int dT = has_delta ? d.T : 0;
+    const int dcol = has_delta ? (int)(sl.y & 0x0FFFFFFFu) : 0;
+    const int du = (int)rr.y;
+    uint32_t mypu = 0;
+    if (du > 2 && lane < du) mypu = A.in_edge[rr.x + lane];            // du <= 64 on this path
+    if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
+    int bval[RC];
+    uint32_t bord[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+    const int64_t erow0 = (int64_t)(rr.x - d.in_base) * dT;
+    const int rowbytes = d.k * 4;
+    for (int t = 0; t < du; t += 2) {
+        const bool two = t + 1 < du;                                    // wave-uniform
+        uint32_t pa, pb;
+        if (du <= 2) { pa = t == 0 ? rr.z : rr.w; pb = rr.w; }
+        else { pa = (uint32_t)__builtin_amdgcn_readlane((int)mypu, t); pb = (uint32_t)__builtin_amdgcn_readlane((int)mypu, two ? t + 1 : t); }
+        const int ia = (int)(pa & 0x7FFFFFFFu), wa = (int)(pa >> 31) + wv;
+        const int ib = (int)(pb & 0x7FFFFFFFu), wb = (int)(pb >> 31) + wv;
+        if (act) {
+            // rows r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
+            // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding: all
+            // loads of both in-edges go out back to back and the select discards what is out of range.
+            const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
+            const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
+            int va[RC], vb[RC];
+            const int dla = (int)dm[erow0 + (int64_t)t * dT + dcol];
+            int dlb = 0;
+#pragma unroll
+            for (int q = 0; q < RC; ++q) va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offa + q * rowbytes, 0, AUX);
+            if (two) {
+                dlb = (int)dm[erow0 + (int64_t)(t + 1) * dT + dcol];
+#pragma unroll
+                for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, AUX);
+            }
+            relax_select<RC>(va, dla, ord_word(ia, j, (int)(pa >> 31), wv), r0, wa, RP, bval, bord);
+            if (two) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(pb >> 31), wv), r0, wb, RP, bval, bord);
+        }
+    }
+    if (PROF) q2 = __builtin_amdgcn_s_memtime();
+    // segmented max over lanes with equal destination column (lanes of a column are adjacent)
+    for (int st = 0, sh = 1; st < steps; ++st, sh <<= 1) {
+        const int oj2 = __shfl_down(j2, sh);
+        const bool same = (lane + sh < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int ov = __shfl_down(bval[q], sh);
+            const uint32_t oo = (uint32_t)__shfl_down((int)bord[q], sh);
+            const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+            bval[q] = take ? ov : bval[q];
+            bord[q] = take ? oo : bord[q];
+        }
+    }
+    const int pj2 = __shfl_up(j2, 1);
+    const bool head = act & ((lane == 0) | (pj2 != j2));
+    unsigned long long dsum = 0;
+    if (PROF) q3 = __builtin_amdgcn_s_memtime();
+    if (head) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int r2 = r0 + q;
+            if (r2 < RP) {
+                const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                nxt[idx] = bval[q];
+                A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                if (DIGEST && bval[q] != NEG_INF) {
+                    const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
+                    dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
+                }
+            }
+        }
+    }
+    if (g == 0 && d.ndead > 0) {                                        // columns nobody owns: unreachable
+        for (int t = lane; t < d.ndead * RC; t += 64) {
+            const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
+            if (r0 + q < RP) {
+                const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
+                nxt[idx] = NEG_INF;
+                A.bp[d.bp_off + idx] = BP_NONE;
+            }
+        }
+    }
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+    if (PROF) { q4 = __builtin_amdgcn_s_memtime(); pp[0] += q1 - q0; pp[1] += q2 - q1; pp[2] += q3 - q2; pp[3] += q4 - q3; }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padded_base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)padded_base, 0, bytes, 0x00020000);
+}
+
+// per-level launch of the fast form: grid = (ceil(ngroups/4), k2 * nchunk), one task per wave
+template <int RC, bool DIGEST>
+__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl) {
+    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (g >= d.ngroups) return;                                         // wave-uniform; no block barrier below
+    const int nchunk = (A.RP + RC - 1) / RC;
+    const int i2 = nchunk == 1 ? (int)blockIdx.y : (int)blockIdx.y / nchunk;
+    const int r0 = nchunk == 1 ? 0 : ((int)blockIdx.y % nchunk) * RC;
+    const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
+    int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    sweep_task<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Team form: ONE launch for the whole level chain.  Workgroups read their XCD id (HW_REG_XCC_ID) and
+// only those that share the elected XCD stay: an XCD's CUs share one L2, so inside the team a level
+// hand-off needs no cache write-back/invalidate -- producers' plain stores are in the L2 once their
+// vmcnt drains, consumers read the state with sc1 loads (L2-served, never from the CU's L1), and the
+// level barrier is one L2 atomic counter.  Read-only graph tables stay warm in L1/L2 for the whole
+// run, which is what the per-level launches cannot offer (every kernel starts cold).  Correctness does
+// not depend on where the dispatcher puts workgroups: a team is DEFINED by the hardware XCC id its
+// members read, whatever its size; every spin is bounded and reports through ctl->error, in which
+// case the host falls back to per-level launches.
+// ---------------------------------------------------------------------------------------------
+struct TeamCtl {
+    uint32_t registered, leader_xcc_plus1, bar, error;
+    uint32_t team_count[8];
+    unsigned long long t_cycles, t_real;                // diagnostic: shader cycles / 100 MHz ticks spent in the level loop (rank 0)
+    unsigned long long phase[6], tphase[4];             // diagnostic (PROF build): cycles per phase, rank 0 wave 0
+};
+
+__device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int RC, bool PROF, int AUX = 16>
+__global__ __launch_bounds__(512) void dp_team_kernel(FastArgs A, const LevelDesc *__restrict__ descs, int lvl_begin, int lvl_end, TeamCtl *ctl) {
+    __shared__ int s_rank, s_size, s_go;
+    const int wave = (int)(threadIdx.x >> 6), nwave_wg = (int)(blockDim.x >> 6);
+    if (threadIdx.x == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        xcc &= 7u;
+        const uint32_t rank = atomicAdd(&ctl->team_count[xcc], 1u);
+        atomicCAS(&ctl->leader_xcc_plus1, 0u, xcc + 1u);
+        __threadfence();
+        atomicAdd(&ctl->registered, 1u);
+        int go = -1;
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {            // every workgroup must be resident: bounded
+            if (ld_sc1(&ctl->registered) >= gridDim.x || ld_sc1(&ctl->error)) { go = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (go < 0) { atomicExch(&ctl->error, 1u); go = 0; }
+        if (ld_sc1(&ctl->error)) go = 0;
+        const uint32_t work = ld_sc1(&ctl->leader_xcc_plus1) - 1u;
+        s_rank = (int)rank;
+        s_size = (int)ld_sc1(&ctl->team_count[work & 7u]);
+        s_go = (go && work == xcc) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const int rank = s_rank, size = s_size;
+    const int wave_id = rank * nwave_wg + wave, n_waves = size * nwave_wg;
+    const int nchunk = (A.RP + RC - 1) / RC;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tp[4] = {0, 0, 0, 0};
+    for (int lvl = lvl_begin; lvl < lvl_end; ++lvl) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (PROF) t0 = __builtin_amdgcn_s_memtime();
+        const LevelDesc d = descs[lvl];
+        if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
+        const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;
+        int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+        const __amdgpu_buffer_rsrc_t rs = state_rsrc(cur, A.buf_bytes);
+        // A lone wave issues ~1 instruction per 4-8 cycles, so on narrow levels the RC-fold unrolled task IS the
+        // critical path: split the recombination counts over more waves (chunks of 1 or 4) while the team has idle waves.
+        const int base_tasks = d.k2 * d.ngroups;
+        if (base_tasks * A.RP <= n_waves) {
+            const int per_row = d.ngroups * A.RP, ntask = d.k2 * per_row;
+            for (int task = wave_id; task < ntask; task += n_waves) {
+                const int i2 = task / per_row, rem = task - i2 * per_row;
+                sweep_task<1, false, AUX, PROF>(A, d, rs, nxt, i2, rem / A.RP, rem % A.RP, lvl, tp);
+            }
+        } else if (RC > 4 && base_tasks * ((A.RP + 3) / 4) <= 2 * n_waves) {
+            const int nc4 = (A.RP + 3) / 4, per_row = d.ngroups * nc4, ntask = d.k2 * per_row;
+            for (int task = wave_id; task < ntask; task += n_waves) {
+                const int i2 = task / per_row, rem = task - i2 * per_row;
+                sweep_task<4, false, AUX, PROF>(A, d, rs, nxt, i2, rem / nc4, (rem % nc4) * 4, lvl, tp);
+            }
+        } else {
+            const int per_row = d.ngroups * nchunk, ntask = d.k2 * per_row;
+            for (int task = wave_id; task < ntask; task += n_waves) {
+                const int i2 = task / per_row, rem = task - i2 * per_row;
+                const int g = nchunk == 1 ? rem : rem / nchunk;
+                const int r0 = nchunk == 1 ? 0 : (rem % nchunk) * RC;
+                sweep_task<RC, false, AUX, PROF>(A, d, rs, nxt, i2, g, r0, lvl, tp);
+            }
+        }
+        if (PROF) t2 = __builtin_amdgcn_s_memtime();
+        // level barrier inside the team (one XCD): drain this wave's stores into the L2, then count
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PROF) t3 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (PROF) t4 = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) {
+            atomicAdd(&ctl->bar, 1u);
+            const uint32_t want = (uint32_t)size * (uint32_t)(lvl - lvl_begin + 1);
+            uint32_t spin = 0;
+            while (ld_sc1(&ctl->bar) < want) {
+                if (++spin > (1u << 22) || ld_sc1(&ctl->error)) { atomicExch(&ctl->error, 2u); break; }
+            }
+        }
+        __syncthreads();
+        if (PROF) { const unsigned long long t5 = __builtin_amdgcn_s_memtime(); ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4; }
+        if (ld_sc1(&ctl->error)) return;
+        if (PROF) ph[5] += __builtin_amdgcn_s_memtime() - t0;
+    }
+    if (PROF && rank == 0 && threadIdx.x == 0) { for (int q = 0; q < 6; ++q) ctl->phase[q] = ph[q]; for (int q = 0; q < 4; ++q) ctl->tphase[q] = tp[q]; }
+    if (rank == 0 && threadIdx.x == 0) { ctl->t_cycles = __builtin_amdgcn_s_memtime() - c0; ctl->t_real = __builtin_amdgcn_s_memrealtime() - w0; }
+}
+
+// plain launch: one level per launch, level given by argument
+template <int RC, bool DIGEST>
+__global__ __launch_bounds__(256) void dp_sweep_kernel(SweepArgs A, int lvl) {
+    sweep_level_pairs<RC, DIGEST>(A, lvl, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), (int)(gridDim.x * 4));
 }
 
 __global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, every r starts at 0 (:534-535)
@@ -195,13 +571,13 @@ __global__ void dp_traceback_kernel(const LevelDesc *__restrict__ descs, int L, 
                                     ColourCsr col, int cap, int32_t *__restrict__ edges /* 4*cap */, TraceOut *out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     TraceOut o;
-    o.value = final_val[R];              // sink level: cell (i=0, j=0, r=R) of a k_sink-wide level
+    o.value = final_val[(int64_t)R * descs[L - 1].k2];   // sink level, layout [i][r][j]: cell (i=0, r=R, j=0)
     o.s_het = 0; o.n_p1 = 0; o.n_p2 = 0; o.overflow = 0;
     if (o.value != NEG_INF) {
         int i = 0, j = 0, r = R;
         for (int l = L - 1; l >= 1; --l) {
             const LevelDesc d = descs[l];
-            const int64_t t = ((int64_t)i * d.k2 + j) * RP + r;
+            const int64_t t = ((int64_t)i * RP + r) * d.k2 + j;
             const uint32_t b = bp[d.bp_off + t];
             const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
             const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
@@ -310,8 +686,16 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         if (n) has_col[level_of[v]] = 1;
     }
     S.cells = S.relaxations = S.edge_pairs = S.colour_entries = 0;
-    S.total_cells = 0; S.max_level_cells = S.RP; S.delta_entries = 0;
-    std::vector<int32_t> dtrans;
+    S.total_cells = 0; S.max_level_cells = S.RP; S.delta_entries = DELTA_PAD;
+    std::vector<int32_t> dtrans, dead_cols;
+    std::vector<uint32_t> grp_begin;
+    std::vector<uint32_t> slots;                 // 2 words per slot, 64 slots per group
+    std::vector<uint32_t> rowrec((size_t)nV * 4, 0);
+    for (int v = 0; v < nV; ++v) {
+        const uint32_t e0 = in_off[v], dv = in_off[v + 1] - e0;
+        rowrec[4 * (size_t)v] = e0; rowrec[4 * (size_t)v + 1] = dv;
+        rowrec[4 * (size_t)v + 2] = dv > 0 ? in_edge[e0] : 0; rowrec[4 * (size_t)v + 3] = dv > 1 ? in_edge[e0 + 1] : 0;
+    }
     std::vector<int64_t> dblk_first;
     int64_t nblk = 0;
     for (int l = 1; l < L; ++l) {
@@ -320,6 +704,50 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         d.b0 = g->level_off[l]; d.k2 = g->level_off[l + 1] - d.b0;
         d.in_base = in_off[d.b0];
         d.T = (int32_t)(in_off[d.b0 + d.k2] - d.in_base);
+        // column groups: greedy runs of whole columns with <= 64 in-edges; a column with more gets its own group
+        d.grp_first = (int32_t)grp_begin.size();
+        d.dead_first = (int32_t)dead_cols.size();
+        {
+            uint32_t cur_size = 0;
+            for (int c = 0; c < d.k2; ++c) {
+                const uint32_t e0 = in_off[d.b0 + c], dv = in_off[d.b0 + c + 1] - e0;
+                if (dv == 0) { dead_cols.push_back(c); continue; }
+                if (cur_size == 0 || cur_size + dv > 64 || dv > 64) { grp_begin.push_back(e0); cur_size = 0; }
+                cur_size += dv;
+                if (dv > 64) cur_size = 65;                      // force a new group after a giant column
+            }
+        }
+        d.ngroups = (int32_t)grp_begin.size() - d.grp_first;
+        grp_begin.push_back(d.in_base + (uint32_t)d.T);          // sentinel: end of the level's in-edges
+        // 64-wide slot table of the fast kernel
+        d.slot_first = (int64_t)(slots.size() / 2);
+        d.fast_ok = (d.T < (1 << 28)) ? 1 : 0;
+        for (int gi = 0; gi < d.ngroups; ++gi) {
+            const uint32_t gb0 = grp_begin[d.grp_first + gi], ge0 = grp_begin[d.grp_first + gi + 1];
+            if (ge0 - gb0 > 64) d.fast_ok = 0;                   // giant column: generic kernel
+            uint32_t maxdv = 1;
+            for (uint32_t e = gb0; e < ge0 && e < gb0 + 64; ) {
+                const int c = in_dst[e] - d.b0;
+                const uint32_t dv = in_off[d.b0 + c + 1] - in_off[d.b0 + c];
+                maxdv = std::max(maxdv, dv);
+                e += dv;
+            }
+            uint32_t steps = 0;
+            while ((1u << steps) < std::min(maxdv, 64u)) ++steps;
+            for (uint32_t q = 0; q < 64; ++q) {
+                const uint32_t e = gb0 + q;
+                if (e < ge0) {
+                    const uint32_t pv = in_edge[e];
+                    slots.push_back((pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16));
+                    slots.push_back((e - d.in_base) | (steps << 28));
+                } else {
+                    slots.push_back(0xFFFFFFFFu);
+                    slots.push_back(steps << 28);
+                }
+            }
+        }
+        d.ndead = (int32_t)dead_cols.size() - d.dead_first;
+        if (d.ngroups == 0) { d.ngroups = 1; grp_begin.push_back(d.in_base + (uint32_t)d.T); }   // level without in-edges: one empty group
         const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
         d.bp_off = S.total_cells;
         S.total_cells += ncell;
@@ -370,12 +798,25 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = upload(S.d_het_col, g->het_col, 4 * (size_t)g->het_off[nV], s)) return rc;
     if (int rc = upload(S.d_dtrans, dtrans.data(), 4 * dtrans.size(), s)) return rc;
     if (int rc = upload(S.d_dblk_first, dblk_first.data(), 8 * dblk_first.size(), s)) return rc;
+    if (int rc = upload(S.d_grp, grp_begin.data(), 4 * grp_begin.size(), s)) return rc;
+    if (int rc = upload(S.d_dead, dead_cols.data(), 4 * dead_cols.size(), s)) return rc;
+    if (int rc = upload(S.d_rowrec, rowrec.data(), 4 * rowrec.size(), s)) return rc;
+    if (int rc = upload(S.d_slots, slots.data(), 4 * slots.size(), s)) return rc;
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
+    DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_bp.ensure(bp_bytes)) return rc;
-    if (int rc = S.d_val[0].ensure(st_bytes / 2)) return rc;
-    if (int rc = S.d_val[1].ensure(st_bytes / 2)) return rc;
+    S.pad_front = 2 * (int64_t)max_k;
+    const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)max_k);
+    if (int rc = S.d_val[0].ensure(st_bytes / 2 + pad_bytes)) return rc;
+    if (int rc = S.d_val[1].ensure(st_bytes / 2 + pad_bytes)) return rc;
+    DG_HIP(hipMemsetAsync(S.d_val[0].p, 0, S.d_val[0].bytes, s));
+    DG_HIP(hipMemsetAsync(S.d_val[1].p, 0, S.d_val[1].bytes, s));
     if (int rc = S.d_digest.ensure(8 * (size_t)L)) return rc;
     if (int rc = S.d_trace.ensure(sizeof(TraceOut))) return rc;
+    if (int rc = S.d_ctrl.ensure(sizeof(TeamCtl) * TEAM_CTL_SLOTS)) return rc;
+    S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
+    S.all_fast = true;
+    for (int l = 1; l < L; ++l) if (!S.descs[l].fast_ok || (int64_t)S.descs[l].k2 * S.descs[l].ngroups * 5 >= ((int64_t)1 << 31)) S.all_fast = false;
     S.cap = R + 8;
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
     DG_HIP(hipStreamSynchronize(s));      // host staging vectors die here
@@ -399,6 +840,8 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     ColourCsr col{S.d_hom_off.as<int64_t>(), S.d_het_off.as<int64_t>(), S.d_hom_col.as<int32_t>(), S.d_het_col.as<int32_t>()};
     const int n_dtrans = (int)(S.d_dtrans.bytes && S.n_delta_blocks ? 0 : 0);
     (void)n_dtrans;
+    bool team_failed = false;
+retry_forward:
     DG_HIP(hipEventRecord(S.ev[0], s));
     int ndt = 0;
     for (int l = 1; l < S.L; ++l) if (S.descs[l].delta_off >= 0) ++ndt;
@@ -408,25 +851,99 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                            S.d_delta.as<uint16_t>());
     DG_HIP(hipEventRecord(S.ev[1], s));
     if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
-    hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, S.d_val[0].as<int32_t>(), S.RP);
-    for (int l = 1; l < S.L; ++l) {
-        const LevelDesc &d = S.descs[l];
-        const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
-        const unsigned grid = (unsigned)std::min<int64_t>((ncell + 255) / 256, S.max_blocks);
-        const int32_t *cur = S.d_val[(l - 1) & 1].as<int32_t>();
-        int32_t *nxt = S.d_val[l & 1].as<int32_t>();
-        if (S.want_digest)
-            hipLaunchKernelGGL(dp_level_kernel<true>, dim3(grid), dim3(256), 0, s, descs, l, S.RP, S.d_in_off.as<uint32_t>(),
-                               S.d_in_edge.as<uint32_t>(), S.d_delta.as<uint16_t>(), cur, nxt, S.d_bp.as<uint32_t>(),
-                               S.d_digest.as<unsigned long long>());
-        else
-            hipLaunchKernelGGL(dp_level_kernel<false>, dim3(grid), dim3(256), 0, s, descs, l, S.RP, S.d_in_off.as<uint32_t>(),
-                               S.d_in_edge.as<uint32_t>(), S.d_delta.as<uint16_t>(), cur, nxt, S.d_bp.as<uint32_t>(),
-                               (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, S.d_val[0].as<int32_t>() + S.pad_front, S.RP);
+    const int rc_sel = S.RP <= 8 ? 8 : (S.RP <= 19 ? 19 : 33);
+    SweepArgs A;
+    A.descs = descs; A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
+    A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
+    A.delta = S.d_delta.as<uint16_t>();
+    A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
+    A.bp = S.d_bp.as<uint32_t>(); A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
+    FastArgs F;
+    F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.dead_cols = A.dead_cols;
+    F.delta = A.delta; F.bp = A.bp; F.digest = A.digest; F.RP = S.RP;
+    F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
+    F.pad_bytes = (int)(4 * S.pad_front);
+    F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
+    const bool small_state = S.state_alloc_bytes < ((size_t)1 << 31);   // 32-bit buffer offsets
+    const int nchunk = (S.RP + rc_sel - 1) / rc_sel;
+    int64_t n_launch = 0;
+    uint32_t team_err = 0;
+    // schedule: runs of narrow levels go to the one-XCD team kernel (one launch per run), wide levels
+    // get one whole-chip launch each.  A level is "narrow" when the team finishes it in <= ~2 task rounds.
+    const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed;
+    S.schedule.clear();
+    {
+        int l = 1;
+        while (l < S.L) {
+            auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok && (int64_t)d.k2 * d.ngroups <= S.team_max_tasks; };
+            int e = l;
+            if (narrow(l)) { while (e < S.L && narrow(e)) ++e; }
+            const bool is_team = e - l >= S.team_min_levels;
+            if (!is_team) e = std::max(e, l + 1);
+            if (!is_team && !S.schedule.empty() && !S.schedule.back().team) S.schedule.back().end = e;
+            else S.schedule.push_back({l, e, is_team});
+            l = e;
+        }
+    }
+    bool team = false;
+    int n_team_launch = 0;
+    for (const auto &seg : S.schedule) {
+        if (seg.team) {
+            TeamCtl *ctl = S.d_ctrl.as<TeamCtl>() + (n_team_launch % TEAM_CTL_SLOTS);
+            DG_HIP(hipMemsetAsync(ctl, 0, sizeof(TeamCtl), s));
+            const dim3 grid((unsigned)S.team_grid);
+#define DG_TEAM(RCV) hipLaunchKernelGGL((dp_team_kernel<RCV, false>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl)
+            if (rc_sel == 19 && getenv("DG_TEAM_PROF")) hipLaunchKernelGGL((dp_team_kernel<19, true>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl);
+            else if (rc_sel == 8) DG_TEAM(8); else if (rc_sel == 19) DG_TEAM(19); else DG_TEAM(33);
+#undef DG_TEAM
+            team = true;
+            ++n_team_launch;
+            ++n_launch;
+            if (n_team_launch % TEAM_CTL_SLOTS == 0) {      // ctl slots are recycled: check the finished ones first
+                std::vector<TeamCtl> hc(TEAM_CTL_SLOTS);
+                DG_HIP(hipMemcpyAsync(hc.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
+                DG_HIP(hipStreamSynchronize(s));
+                for (auto &h : hc) if (h.error) { team_err = h.error; }
+                if (team_err) break;
+            }
+            continue;
+        }
+        for (int l = seg.begin; l < seg.end; ++l) {
+            const LevelDesc &d = S.descs[l];
+            if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
+                // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
+                // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
+                const int64_t base = (int64_t)d.k2 * d.ngroups;
+                int rc = rc_sel;
+                if (S.adaptive_rc) {
+                    if (base * S.RP <= S.chip_waves) rc = 1;
+                    else if (base * ((S.RP + 1) / 2) <= S.chip_waves) rc = 2;
+                    else if (base * ((S.RP + 3) / 4) <= S.chip_waves) rc = 4;
+                    if (rc > rc_sel) rc = rc_sel;
+                }
+                const int nch = (S.RP + rc - 1) / rc;
+                const dim3 grid((unsigned)((d.ngroups + 3) / 4), (unsigned)(d.k2 * nch));
+#define DG_FAST(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG>), grid, dim3(256), 0, s, F, d, l)
+#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
+                                        case 8: DG_FAST(8, DG); break; case 19: DG_FAST(19, DG); break; default: DG_FAST(33, DG); break; } } while (0)
+                if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
+#undef DG_FAST_RC
+#undef DG_FAST
+            } else {
+                const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
+                const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
+#define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
+                if (S.want_digest) { if (rc_sel == 8) DG_SWEEP(8, true); else if (rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
+                else { if (rc_sel == 8) DG_SWEEP(8, false); else if (rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
+#undef DG_SWEEP
+            }
+            ++n_launch;
+        }
     }
     DG_HIP(hipEventRecord(S.ev[2], s));
     hipLaunchKernelGGL(dp_traceback_kernel, dim3(1), dim3(64), 0, s, descs, S.L, S.RP, S.R, S.d_bp.as<uint32_t>(),
-                       S.d_val[(S.L - 1) & 1].as<int32_t>(), col, S.cap, S.d_edges.as<int32_t>(), S.d_trace.as<TraceOut>());
+                       S.d_val[(S.L - 1) & 1].as<int32_t>() + S.pad_front, col, S.cap, S.d_edges.as<int32_t>(), S.d_trace.as<TraceOut>());
     DG_HIP(hipEventRecord(S.ev[3], s));
     DG_HIP(hipGetLastError());
     TraceOut to;
@@ -437,12 +954,35 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         S.digest_host.assign(S.L, 0);
         DG_HIP(hipMemcpyAsync(S.digest_host.data(), S.d_digest.p, 8 * (size_t)S.L, hipMemcpyDeviceToHost, s));
     }
+    std::vector<TeamCtl> ctl_host(TEAM_CTL_SLOTS);
+    memset(ctl_host.data(), 0, sizeof(TeamCtl) * TEAM_CTL_SLOTS);
+    if (team) DG_HIP(hipMemcpyAsync(ctl_host.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
+    for (auto &h : ctl_host) if (h.error) team_err = h.error;
+    if (team && team_err) {             // a team could not form or a spin timed out: redo with per-level launches
+        fprintf(stderr, "[dipgenie_hip] team kernel reported code %u; falling back to per-level launches\n", team_err);
+        team_failed = true;
+        S.team_fallbacks++;
+        goto retry_forward;
+    }
+    S.last_team_size = team ? (int)ctl_host[0].team_count[(ctl_host[0].leader_xcc_plus1 - 1) & 7] : 0;
+    if (team && getenv("DG_DEBUG")) {
+        int nt = 0; int64_t nl = 0;
+        for (auto &sg : S.schedule) if (sg.team) { ++nt; nl += sg.end - sg.begin; }
+        fprintf(stderr, "[dipgenie_hip] schedule: %d team launches covering %lld of %d levels; team size %d of %u WGs; last team: %.3f ms, shader clock %.0f MHz\n", nt, (long long)nl,
+                S.L - 1, S.last_team_size, ctl_host[0].registered, ctl_host[0].t_real / 1e5, ctl_host[0].t_real ? 100.0 * ctl_host[0].t_cycles / ctl_host[0].t_real : 0.0);
+    }
+    if (team && getenv("DG_TEAM_PROF")) {
+        const TeamCtl &h = ctl_host[0];
+        const double nl = 1.0;
+        fprintf(stderr, "[dipgenie_hip] slot0 cycles: desc %.0f tasks %.0f drain %.0f sync1 %.0f barrier %.0f total %.0f | tables %.0f relax %.0f reduce %.0f store %.0f\n", h.phase[0] / nl, h.phase[1] / nl,
+                h.phase[2] / nl, h.phase[3] / nl, h.phase[4] / nl, h.phase[5] / nl, h.tphase[0] / nl, h.tphase[1] / nl, h.tphase[2] / nl, h.tphase[3] / nl);
+    }
     DG_HIP(hipEventElapsedTime(&S.timing.delta_ms, S.ev[0], S.ev[1]));
     DG_HIP(hipEventElapsedTime(&S.timing.forward_ms, S.ev[1], S.ev[2]));
     DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
-    S.timing.n_forward_launches = S.L - 1;
+    S.timing.n_forward_launches = n_launch;
     if (to.overflow || to.n_p1 > S.cap || to.n_p2 > S.cap) { set_error("traceback edge list overflow (%d, %d > %d)", to.n_p1, to.n_p2, S.cap); return DG_ERR_STATE; }
     res->value = to.value; res->s_het = to.s_het; res->n_p1 = to.n_p1; res->n_p2 = to.n_p2;
     res->cells = S.cells; res->relaxations = S.relaxations;
@@ -486,7 +1026,13 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     if (!c || !key) { dgi::set_error("dg_dp_set_option: null"); return DG_ERR_ARG; }
     if (!c->dp) c->dp = new dgi::DpState();
     if (!strcmp(key, "digest")) c->dp->want_digest = v;
-    else if (!strcmp(key, "graph")) c->dp->use_graph = v;
+    else if (!strcmp(key, "fast")) c->dp->use_fast = v;
+    else if (!strcmp(key, "team")) c->dp->use_team = v;
+    else if (!strcmp(key, "team_grid")) c->dp->team_grid = v > 0 ? v : 256;
+    else if (!strcmp(key, "team_max_tasks")) c->dp->team_max_tasks = v;
+    else if (!strcmp(key, "team_min_levels")) c->dp->team_min_levels = v;
+    else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
+    else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;
     else if (!strcmp(key, "max_blocks")) c->dp->max_blocks = v > 0 ? v : 2048;
     else { dgi::set_error("unknown option %s", key); return DG_ERR_ARG; }
     return DG_OK;

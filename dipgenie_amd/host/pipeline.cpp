@@ -795,6 +795,7 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     sum.n_vertices = nV;
     stamp("dp_prologue_flatten", t0);
     if (!opt.dump_prefix.empty()) dpg.save(opt.dump_prefix + ".dpg", opt.R);
+    if (opt.dump_only) { err = "dump_only"; return 1; }
 
     // ---- the level loop + sink read-out: DEVICE (approximator.cpp:532-716, 774-785) ----
     t0 = now_s();

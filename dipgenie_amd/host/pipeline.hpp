@@ -42,6 +42,7 @@ struct Options {
     bool quiet = false;       // (ours) suppress progress chatter
     std::string gfa_file, reads_file, hap_file;   // -g -r -o
     std::string dump_prefix;  // (ours) if set, dump the levelized DP graph to <prefix>.dpg
+    bool dump_only = false;   // (ours, tests) stop after the dump
 };
 
 struct ExpandedGraph {        // ExpandedGraph.hpp:16-26

@@ -50,7 +50,7 @@ int main(int argc, char **argv) {
     dg::Pipeline p;
     std::string json;
     int c;
-    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:q")) >= 0) {
+    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:qX")) >= 0) {
         switch (c) {
         case 't': p.opt.threads = atoi(optarg); break;
         case 'p': p.opt.ploidy = atoi(optarg); break;
@@ -65,6 +65,7 @@ int main(int argc, char **argv) {
         case 'D': p.opt.dump_prefix = optarg; break;
         case 'J': json = optarg; break;
         case 'q': p.opt.quiet = true; break;
+        case 'X': p.opt.dump_only = true; break;
         }
     }
     p.be.sketch_reads = o_sketch_reads;
@@ -73,7 +74,7 @@ int main(int argc, char **argv) {
     p.be.free_buf = orc_free;
     p.be.last_error = o_err;
     std::string err;
-    if (p.run(err) != 0) { fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
+    if (p.run(err) != 0) { if (err == "dump_only") return 0; fprintf(stderr, "error: %s\n", err.c_str()); return 1; }
     if (!json.empty()) {
         FILE *f = fopen(json.c_str(), "w");
         fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "

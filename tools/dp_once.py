@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Run the HIP DP once on a .dpg (for rocprofv3). usage: dp_once.py graph.dpg [graph_mode] [n_runs]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dipgenie_amd import capi
+ctx = capi.Context(0)
+g = capi.DpGraphArrays.load(sys.argv[1])
+ctx.dp_set_option("fast", int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx.dp_load_graph(g)
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+    out = ctx.dp_run()
+tm = ctx.dp_timing()
+print("value", out.value, "fwd_ms", tm.forward_ms, "tb_ms", tm.traceback_ms)
