@@ -40,7 +40,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
 };
 
 struct TraceOut {
-    int32_t value, s_het, n_p1, n_p2, overflow, pad[3];
+    int32_t value, s_het, n_e, overflow;
 };
 
 struct DpState {
@@ -57,7 +57,7 @@ struct DpState {
     uint64_t cells = 0, relaxations = 0, edge_pairs = 0, colour_entries = 0;
     int64_t total_cells = 0, max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots;
+    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path;
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -355,31 +355,58 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
     const int64_t erow0 = (int64_t)(rr.x - d.in_base) * dT;
     const int rowbytes = d.k * 4;
-    for (int t = 0; t < du; t += 2) {
-        const bool two = t + 1 < du;                                    // wave-uniform
-        uint32_t pa, pb;
-        if (du <= 2) { pa = t == 0 ? rr.z : rr.w; pb = rr.w; }
-        else { pa = (uint32_t)__builtin_amdgcn_readlane((int)mypu, t); pb = (uint32_t)__builtin_amdgcn_readlane((int)mypu, two ? t + 1 : t); }
-        const int ia = (int)(pa & 0x7FFFFFFFu), wa = (int)(pa >> 31) + wv;
-        const int ib = (int)(pb & 0x7FFFFFFFu), wb = (int)(pb >> 31) + wv;
-        if (act) {
-            // rows r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
-            // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding: all
-            // loads of both in-edges go out back to back and the select discards what is out of range.
+    // Source rows are r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
+    // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding; the select
+    // discards what is out of range, which lets every load be issued unconditionally, back to back.
+    if (du <= 2) {
+        // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
+        if (act && du > 0) {
+            const int ia = (int)(rr.z & 0x7FFFFFFFu), wa = (int)(rr.z >> 31) + wv;
+            const int ib = (int)(rr.w & 0x7FFFFFFFu), wb = (int)(rr.w >> 31) + wv;
             const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
             const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
             int va[RC], vb[RC];
-            const int dla = (int)dm[erow0 + (int64_t)t * dT + dcol];
+            const int dla = (int)dm[erow0 + dcol];
             int dlb = 0;
 #pragma unroll
             for (int q = 0; q < RC; ++q) va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offa + q * rowbytes, 0, AUX);
-            if (two) {
-                dlb = (int)dm[erow0 + (int64_t)(t + 1) * dT + dcol];
+            if (du == 2) {
+                dlb = (int)dm[erow0 + dT + dcol];
 #pragma unroll
                 for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, AUX);
             }
-            relax_select<RC>(va, dla, ord_word(ia, j, (int)(pa >> 31), wv), r0, wa, RP, bval, bord);
-            if (two) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(pb >> 31), wv), r0, wb, RP, bval, bord);
+            relax_select<RC>(va, dla, ord_word(ia, j, (int)(rr.z >> 31), wv), r0, wa, RP, bval, bord);
+            if (du == 2) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(rr.w >> 31), wv), r0, wb, RP, bval, bord);
+        }
+    } else {
+        // heavy rows (recombination fan-in): U in-edges per step -- all their loads (U deltas + U*RC values) go out
+        // back to back, then the selects run; (value, ord) max is associative and commutative, so the order inside
+        // a step is irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
+        constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : (RC >= 2 ? 8 : 16));
+        for (int t = 0; t < du; t += U) {
+            uint32_t pu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pu[u] = (uint32_t)__builtin_amdgcn_readlane((int)mypu, min(t + u, du - 1));
+            if (act) {
+                int vals[U][RC], dl[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (t + u < du) {                                   // wave-uniform
+                        const int iu = (int)(pu[u] & 0x7FFFFFFFu), w = (int)(pu[u] >> 31) + wv;
+                        const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
+                        dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
+#pragma unroll
+                        for (int q = 0; q < RC; ++q) vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, off + q * rowbytes, 0, AUX);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (t + u < du) {
+                        const int iu = (int)(pu[u] & 0x7FFFFFFFu), wu = (int)(pu[u] >> 31);
+                        relax_select<RC>(vals[u], dl[u], ord_word(iu, j, wu, wv), r0, wu + wv, RP, bval, bord);
+                    }
+                }
+            }
         }
     }
     if (PROF) q2 = __builtin_amdgcn_s_memtime();
@@ -563,39 +590,75 @@ __global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, ever
 }
 
 // ---------------------------------------------------------------------------------------------
-// traceback: walk the back-pointer lattice from the sink cell (r = R, i = j = 0)   (:757-785)
-// Emits the weighted-edge lists in REVERSE path order; the host reverses them.
+// traceback   (approximator.cpp:757-785)
+// Phase 1 (wave 0): walk the back-pointer lattice from the sink cell (r = R, i = j = 0).  The chain is one
+// dependent HBM load per level, so everything else is kept off it: the level descriptors of the next 64
+// levels are fetched one per lane and broadcast with readlane, and the hop words are parked in path[].
+// Phase 2 (all 1024 threads, levels in parallel): re-derive s_het from the colour lists of the winning
+// edge pairs (:662) and emit the weighted edges (:673-692; both final edges unconditionally) as
+// (level, from, to, which) records; the host orders them by level.
 // ---------------------------------------------------------------------------------------------
-__global__ void dp_traceback_kernel(const LevelDesc *__restrict__ descs, int L, int RP, int R,
-                                    const uint32_t *__restrict__ bp, const int32_t *__restrict__ final_val,
-                                    ColourCsr col, int cap, int32_t *__restrict__ edges /* 4*cap */, TraceOut *out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    TraceOut o;
-    o.value = final_val[(int64_t)R * descs[L - 1].k2];   // sink level, layout [i][r][j]: cell (i=0, r=R, j=0)
-    o.s_het = 0; o.n_p1 = 0; o.n_p2 = 0; o.overflow = 0;
-    if (o.value != NEG_INF) {
-        int i = 0, j = 0, r = R;
-        for (int l = L - 1; l >= 1; --l) {
-            const LevelDesc d = descs[l];
-            const int64_t t = ((int64_t)i * RP + r) * d.k2 + j;
-            const uint32_t b = bp[d.bp_off + t];
-            const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
-            const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
-            const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
-            if (d.delta_off >= 0) o.s_het += score_symd(col, u1, v1, u2, v2);       // :662
-            const int reps = (l == L - 1) ? 1 : 0;   // final edges are appended unconditionally (:684-692)
-            for (int q = 0; q < reps + wu; ++q) {    // reverse order: the unconditional one first, then the weighted one
-                if (o.n_p1 < cap) { edges[o.n_p1] = u1; edges[cap + o.n_p1] = u2; } else o.overflow = 1;
-                ++o.n_p1;
+__global__ __launch_bounds__(1024) void dp_traceback_kernel(const LevelDesc *__restrict__ descs, int L, int RP, int R,
+                                                            const uint32_t *__restrict__ bp, const int32_t *__restrict__ final_val,
+                                                            ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
+                                                            uint32_t *__restrict__ path /* L */, TraceOut *out) {
+    __shared__ int s_value, s_shet, s_ne;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        const int value = final_val[(int64_t)R * descs[L - 1].k2];   // sink level, layout [i][r][j]: cell (i=0, r=R, j=0)
+        if (threadIdx.x == 0) { s_value = value; s_shet = 0; s_ne = 0; }
+        if (value != NEG_INF) {
+            int i = 0, j = 0, r = R;                                  // wave-uniform
+            for (int base = L - 1; base >= 1; base -= 64) {
+                const int my_l = base - lane;
+                long long bo = 0;
+                int kk = 1;
+                if (my_l >= 1) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; }
+                const int n = min(64, base);
+                for (int t = 0; t < n; ++t) {
+                    const int l = base - t;
+                    const long long bo_l = ((long long)__builtin_amdgcn_readlane((int)(bo >> 32), t) << 32) |
+                                           (unsigned int)__builtin_amdgcn_readlane((int)bo, t);
+                    const int k2 = __builtin_amdgcn_readlane(kk, t);
+                    const uint32_t b = bp[bo_l + ((long long)i * RP + r) * k2 + j];
+                    if (lane == 0) path[l] = b;
+                    i = (int)(b & 0x7FFFu); j = (int)((b >> 15) & 0x7FFFu);
+                    r -= (int)((b >> 30) & 1u) + (int)(b >> 31);
+                }
             }
-            for (int q = 0; q < reps + wv; ++q) {
-                if (o.n_p2 < cap) { edges[2 * cap + o.n_p2] = v1; edges[3 * cap + o.n_p2] = v2; } else o.overflow = 1;
-                ++o.n_p2;
-            }
-            i = pi; j = pj; r -= wu + wv;
         }
     }
-    *out = o;
+    __threadfence_block();
+    __syncthreads();
+    if (s_value != NEG_INF) {
+        int shet = 0;
+        for (int l = 1 + (int)threadIdx.x; l < L; l += (int)blockDim.x) {
+            const uint32_t b = path[l];
+            int i = 0, j = 0;                                         // destination cell at level l = predecessor recorded at l+1
+            if (l < L - 1) { const uint32_t nb = path[l + 1]; i = (int)(nb & 0x7FFFu); j = (int)((nb >> 15) & 0x7FFFu); }
+            const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
+            const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
+            const LevelDesc d = descs[l];
+            const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
+            if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
+            const int reps = (l == L - 1) ? 1 : 0;
+            for (int q = 0; q < reps + wu; ++q) {
+                const int e = atomicAdd(&s_ne, 1);
+                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = u1; edges[2 * cap_e + e] = u2; edges[3 * cap_e + e] = 0; }
+            }
+            for (int q = 0; q < reps + wv; ++q) {
+                const int e = atomicAdd(&s_ne, 1);
+                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = v1; edges[2 * cap_e + e] = v2; edges[3 * cap_e + e] = 1; }
+            }
+        }
+        if (shet) atomicAdd(&s_shet, shet);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TraceOut o;
+        o.value = s_value; o.s_het = s_shet; o.n_e = s_ne; o.overflow = s_ne > cap_e ? 1 : 0;
+        *out = o;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,8 +880,9 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
     S.all_fast = true;
     for (int l = 1; l < L; ++l) if (!S.descs[l].fast_ok || (int64_t)S.descs[l].k2 * S.descs[l].ngroups * 5 >= ((int64_t)1 << 31)) S.all_fast = false;
-    S.cap = R + 8;
+    S.cap = 2 * (R + 8);                               // edge records of both paths
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
+    if (int rc = S.d_path.ensure(4 * (size_t)L)) return rc;
     DG_HIP(hipStreamSynchronize(s));      // host staging vectors die here
     for (auto &e : S.ev) if (!e) DG_HIP(hipEventCreate(&e));
     memset(&S.timing, 0, sizeof S.timing);
@@ -942,8 +1006,9 @@ retry_forward:
         }
     }
     DG_HIP(hipEventRecord(S.ev[2], s));
-    hipLaunchKernelGGL(dp_traceback_kernel, dim3(1), dim3(64), 0, s, descs, S.L, S.RP, S.R, S.d_bp.as<uint32_t>(),
-                       S.d_val[(S.L - 1) & 1].as<int32_t>() + S.pad_front, col, S.cap, S.d_edges.as<int32_t>(), S.d_trace.as<TraceOut>());
+    hipLaunchKernelGGL(dp_traceback_kernel, dim3(1), dim3(1024), 0, s, descs, S.L, S.RP, S.R, S.d_bp.as<uint32_t>(),
+                       S.d_val[(S.L - 1) & 1].as<int32_t>() + S.pad_front, col, S.cap, S.d_edges.as<int32_t>(), S.d_path.as<uint32_t>(),
+                       S.d_trace.as<TraceOut>());
     DG_HIP(hipEventRecord(S.ev[3], s));
     DG_HIP(hipGetLastError());
     TraceOut to;
@@ -983,17 +1048,20 @@ retry_forward:
     DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
     S.timing.n_forward_launches = n_launch;
-    if (to.overflow || to.n_p1 > S.cap || to.n_p2 > S.cap) { set_error("traceback edge list overflow (%d, %d > %d)", to.n_p1, to.n_p2, S.cap); return DG_ERR_STATE; }
-    res->value = to.value; res->s_het = to.s_het; res->n_p1 = to.n_p1; res->n_p2 = to.n_p2;
+    if (to.overflow || to.n_e > S.cap) { set_error("traceback edge list overflow (%d > %d)", to.n_e, S.cap); return DG_ERR_STATE; }
+    res->value = to.value; res->s_het = to.s_het;
     res->cells = S.cells; res->relaxations = S.relaxations;
-    for (int q = 0; q < to.n_p1; ++q) {       // device order is sink -> source
-        const int src = to.n_p1 - 1 - q;
-        if (q < res->cap && res->p1_from && res->p1_to) { res->p1_from[q] = edges[src]; res->p1_to[q] = edges[S.cap + src]; }
+    // records arrive in arbitrary order: path order = ascending level (the two records of the last level are equal)
+    std::vector<int> order(to.n_e);
+    for (int q = 0; q < to.n_e; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return edges[a] < edges[b]; });
+    int n1 = 0, n2 = 0;
+    for (int q : order) {
+        const int from = edges[S.cap + q], tov = edges[2 * S.cap + q];
+        if (edges[3 * S.cap + q] == 0) { if (n1 < res->cap && res->p1_from && res->p1_to) { res->p1_from[n1] = from; res->p1_to[n1] = tov; } ++n1; }
+        else { if (n2 < res->cap && res->p2_from && res->p2_to) { res->p2_from[n2] = from; res->p2_to[n2] = tov; } ++n2; }
     }
-    for (int q = 0; q < to.n_p2; ++q) {
-        const int src = to.n_p2 - 1 - q;
-        if (q < res->cap && res->p2_from && res->p2_to) { res->p2_from[q] = edges[2 * S.cap + src]; res->p2_to[q] = edges[3 * S.cap + src]; }
-    }
+    res->n_p1 = n1; res->n_p2 = n2;
     return DG_OK;
 }
 
