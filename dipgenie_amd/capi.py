@@ -47,7 +47,7 @@ class SketchTiming(C.Structure):
 # every symbol include/dipgenie_hip.h declares
 SYMBOLS = [
     "dg_create", "dg_destroy", "dg_last_error", "dg_set_stream", "dg_synchronize", "dg_device_info",
-    "dg_dp_load_graph", "dg_dp_run", "dg_dp_get_timing", "dg_dp_solve_diploid", "dg_dp_get_level_digest",
+    "dg_dp_prealloc", "dg_dp_load_graph", "dg_dp_run", "dg_dp_get_timing", "dg_dp_solve_diploid", "dg_dp_get_level_digest",
     "dg_dp_set_option", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
 ]
@@ -60,6 +60,7 @@ lib.dg_last_error.restype = C.c_char_p
 lib.dg_set_stream.argtypes = [C.c_void_p, C.c_void_p]
 lib.dg_synchronize.argtypes = [C.c_void_p]
 lib.dg_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+lib.dg_dp_prealloc.argtypes = [C.c_void_p, C.c_int64]
 lib.dg_dp_load_graph.argtypes = [C.c_void_p, C.POINTER(DpGraph)]
 lib.dg_dp_run.argtypes = [C.c_void_p, C.POINTER(DpResult)]
 lib.dg_dp_get_timing.argtypes = [C.c_void_p, C.POINTER(DpTiming)]

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <thread>
 
 #include "dg_internal.hpp"
 
@@ -61,10 +63,16 @@ struct DpState {
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // background reservation of the back-pointer lattice (dg_dp_prealloc): a 100+ GB hipMalloc takes seconds
+    std::thread pre_thread;
+    void *pre_ptr = nullptr;
+    size_t pre_bytes = 0;
 };
 
 void dp_state_free(DpState *s) {
     if (!s) return;
+    if (s->pre_thread.joinable()) s->pre_thread.join();
+    if (s->pre_ptr) (void)hipFree(s->pre_ptr);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -670,7 +678,12 @@ static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
     return DG_OK;
 }
 
+static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    double tl0 = wall_s();
+    auto lap = [&](const char *what) { if (dbg) { double t = wall_s(); fprintf(stderr, "[dipgenie_hip] load: %-22s %.3f s\n", what, t - tl0); tl0 = t; } };
     if (!g || !g->level_off || !g->out_off || !g->out_dst || !g->out_w || !g->hom_off || !g->het_off) {
         set_error("dg_dp_load_graph: null array"); return DG_ERR_ARG;
     }
@@ -726,6 +739,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
                 set_error("parallel edges with different weights into vertex %d: tie order would be schedule dependent", v);
                 return DG_ERR_UNSUPPORTED;
             }
+    lap("validate + in-CSR");
     // colour lists must be sorted (the merges rely on it) and fit the uint16 delta
     int64_t max_list = 0;
     for (int v = 0; v < nV; ++v) {
@@ -740,6 +754,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     }
     if (max_list * 4 > 65535) { set_error("colour lists too long for uint16 score deltas (%lld)", (long long)max_list); return DG_ERR_UNSUPPORTED; }
 
+    lap("colour checks");
     // level descriptors
     S.descs.assign(L, LevelDesc{});
     std::vector<uint8_t> has_col(L, 0);
@@ -838,6 +853,15 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.n_delta_blocks = nblk;
     if (nblk >= (int64_t)1 << 31) { set_error("delta grid too large"); return DG_ERR_UNSUPPORTED; }
 
+    lap("descs + groups + slots");
+    // adopt the background reservation, if any
+    if (S.pre_thread.joinable()) S.pre_thread.join();
+    if (S.pre_ptr) {
+        if (S.pre_bytes > S.d_bp.bytes) { S.d_bp.release(); S.d_bp.p = S.pre_ptr; S.d_bp.bytes = S.pre_bytes; }
+        else (void)hipFree(S.pre_ptr);
+        S.pre_ptr = nullptr; S.pre_bytes = 0;
+    }
+    lap("join prealloc");
     // memory budget
     const size_t bp_bytes = (size_t)S.total_cells * 4, st_bytes = (size_t)S.max_level_cells * 4 * 2,
                  dl_bytes = (size_t)S.delta_entries * 2;
@@ -865,6 +889,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = upload(S.d_dead, dead_cols.data(), 4 * dead_cols.size(), s)) return rc;
     if (int rc = upload(S.d_rowrec, rowrec.data(), 4 * rowrec.size(), s)) return rc;
     if (int rc = upload(S.d_slots, slots.data(), 4 * slots.size(), s)) return rc;
+    lap("table uploads");
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_bp.ensure(bp_bytes)) return rc;
@@ -884,6 +909,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
     if (int rc = S.d_path.ensure(4 * (size_t)L)) return rc;
     DG_HIP(hipStreamSynchronize(s));      // host staging vectors die here
+    lap("allocs + sync");
     for (auto &e : S.ev) if (!e) DG_HIP(hipEventCreate(&e));
     memset(&S.timing, 0, sizeof S.timing);
     S.timing.edge_pairs = S.edge_pairs;
@@ -1078,6 +1104,25 @@ extern "C" int dg_dp_run(dg_ctx *c, dg_dp_result *r) {
 extern "C" int dg_dp_solve_diploid(dg_ctx *c, const dg_dp_graph *g, dg_dp_result *r) {
     if (int rc = dg_dp_load_graph(c, g)) return rc;
     return dg_dp_run(c, r);
+}
+extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
+    if (int rc = dgi::bind(c)) return rc;
+    if (!c->dp) c->dp = new dgi::DpState();
+    dgi::DpState &S = *c->dp;
+    if (S.pre_thread.joinable() || S.pre_ptr) return DG_OK;           // already reserving
+    size_t free_b = 0, total_b = 0;
+    DG_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t want = bytes > 0 ? (size_t)bytes : (size_t)(0.6 * (double)free_b);
+    if (want + ((size_t)8 << 30) > free_b) want = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
+    if (want <= S.d_bp.bytes || want == 0) return DG_OK;
+    const int dev = c->device;
+    dgi::DpState *Sp = &S;
+    S.pre_thread = std::thread([dev, want, Sp]() {
+        if (hipSetDevice(dev) != hipSuccess) return;
+        void *p = nullptr;
+        if (hipMalloc(&p, want) == hipSuccess) { Sp->pre_ptr = p; Sp->pre_bytes = want; }
+    });
+    return DG_OK;
 }
 extern "C" int dg_dp_get_timing(dg_ctx *c, dg_dp_timing *t) {
     if (!c || !c->dp || !t) { dgi::set_error("dg_dp_get_timing: no state"); return DG_ERR_STATE; }

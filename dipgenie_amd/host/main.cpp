@@ -20,6 +20,7 @@ static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint6
     return dg_sketch_haplotype((dg_ctx *)c, s, len, k, w, h, p, n);
 }
 static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
+static void b_hint(void *c) { dg_dp_prealloc((dg_ctx *)c, 0); }   // overlap the lattice reservation with the host stages
 
 static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
     fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");
@@ -76,6 +77,7 @@ int main(int argc, char **argv) {
     p.be.sketch_haplotype = b_sketch_hap;
     p.be.dp_solve_diploid = b_dp;
     p.be.free_buf = dg_free;
+    p.be.hint_dp_soon = b_hint;
     p.be.last_error = dg_last_error;
     double t0 = dg::now_s();
     std::string err;

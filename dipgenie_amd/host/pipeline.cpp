@@ -207,6 +207,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
 
     // ---- compute_anchors (solver.cpp:415-446, 560-575): hap minimizers whose hash is in Sp_R ----
     t0 = now_s();
+    if (opt.ploidy == 2 && be.hint_dp_soon) be.hint_dp_soon(be.ctx);   // device work of the sketches is done: reserve the DP lattice now
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
     std::vector<std::vector<int32_t>> ids(num_walks);
@@ -233,50 +234,77 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     // ---- shared-anchor filter (:590-633) + occurrence sort (:641-663) ----
     occs.clear(); vpool.clear();
     const float thr = opt.threshold * num_walks;                       // float * uint32 -> float (:618)
-    std::vector<std::string> keys;
-    std::vector<int32_t> order, grp;
-    for (int32_t r = 0; r < count_sp_r; ++r) {
-        const int64_t b = bucket_off[r], e = bucket_off[r + 1];
-        if (b == e) continue;
-        const int32_t n = (int32_t)(e - b);
-        keys.resize(n);
-        for (int32_t t = 0; t < n; ++t) {                              // :600-603 "v0_v1_..._"
-            const Raw &o = raw[b + t];
-            const auto &ix = kmer_index[o.h];
-            std::string &s = keys[t];
-            s.clear();
-            for (uint32_t q = ix.voff[o.m]; q < ix.voff[o.m + 1]; ++q) { s += std::to_string(ix.v[q]); s += '_'; }
-        }
-        order.resize(n);
-        std::iota(order.begin(), order.end(), 0);
-        // std::map<std::string,...> iteration = lexicographic on the key; inside a key, push order
-        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return keys[x] < keys[y]; });
-        bool all_haps = false;                                         // :615-622
-        for (int32_t i = 0; i < n;) {
-            int32_t j = i + 1;
-            while (j < n && keys[order[j]] == keys[order[i]]) ++j;
-            if ((float)(j - i) >= thr) { all_haps = true; break; }
-            i = j;
-        }
-        if (all_haps) continue;                                        // :624-632 id dropped entirely
-        // Anchor_hits_1[r][h] in map-iteration order, then std::sort per (r,h) (:641-663)
-        for (uint32_t h = 0; h < num_walks; ++h) {
-            grp.clear();
-            for (int32_t i = 0; i < n; ++i) if (raw[b + order[i]].h == (int32_t)h) grp.push_back(order[i]);
-            if (grp.empty()) continue;
-            const auto &ix = kmer_index[h];
-            std::sort(grp.begin(), grp.end(), [&](int32_t x, int32_t y) {
-                const uint32_t mx = raw[b + x].m, my = raw[b + y].m;
-                const int32_t ax0 = ix.v[ix.voff[mx]], ay0 = ix.v[ix.voff[my]];
-                if (ax0 != ay0) return ax0 < ay0;
-                return ix.v[ix.voff[mx + 1] - 1] < ix.v[ix.voff[my + 1] - 1];
-            });
-            for (int32_t x : grp) {
-                const uint32_t m = raw[b + x].m;
-                Occ o{r, (int32_t)h, (uint32_t)vpool.size(), ix.voff[m + 1] - ix.voff[m]};
-                vpool.insert(vpool.end(), ix.v.begin() + ix.voff[m], ix.v.begin() + ix.voff[m + 1]);
-                occs.push_back(o);
+    // ids are independent (the reference runs this loop under OpenMP too, :593): contiguous id chunks balanced by
+    // occurrence count, each with private output, concatenated in id order afterwards
+    const int n_chunks = std::max(1, opt.threads * 4);
+    std::vector<int32_t> chunk_lo(n_chunks + 1, count_sp_r);
+    chunk_lo[0] = 0;
+    for (int c = 1; c < n_chunks; ++c) {
+        const int64_t want = (int64_t)raw.size() * c / n_chunks;
+        chunk_lo[c] = (int32_t)(std::lower_bound(bucket_off.begin(), bucket_off.end(), want) - bucket_off.begin());
+        chunk_lo[c] = std::min(std::max(chunk_lo[c], chunk_lo[c - 1]), count_sp_r);
+    }
+    std::vector<std::vector<Occ>> occs_c(n_chunks);
+    std::vector<std::vector<int32_t>> vpool_c(n_chunks);
+#pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
+    for (int c = 0; c < n_chunks; ++c) {
+        std::vector<std::string> keys;
+        std::vector<int32_t> order, grp;
+        auto &occs_l = occs_c[c];
+        auto &vpool_l = vpool_c[c];
+        for (int32_t r = chunk_lo[c]; r < chunk_lo[c + 1]; ++r) {
+            const int64_t b = bucket_off[r], e = bucket_off[r + 1];
+            if (b == e) continue;
+            const int32_t n = (int32_t)(e - b);
+            keys.resize(n);
+            for (int32_t t = 0; t < n; ++t) {                          // :600-603 "v0_v1_..._"
+                const Raw &o = raw[b + t];
+                const auto &ix = kmer_index[o.h];
+                std::string &s = keys[t];
+                s.clear();
+                for (uint32_t q = ix.voff[o.m]; q < ix.voff[o.m + 1]; ++q) { s += std::to_string(ix.v[q]); s += '_'; }
             }
+            order.resize(n);
+            std::iota(order.begin(), order.end(), 0);
+            // std::map<std::string,...> iteration = lexicographic on the key; inside a key, push order
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return keys[x] < keys[y]; });
+            bool all_haps = false;                                     // :615-622
+            for (int32_t i = 0; i < n;) {
+                int32_t j = i + 1;
+                while (j < n && keys[order[j]] == keys[order[i]]) ++j;
+                if ((float)(j - i) >= thr) { all_haps = true; break; }
+                i = j;
+            }
+            if (all_haps) continue;                                    // :624-632 id dropped entirely
+            // Anchor_hits_1[r][h] in map-iteration order, then std::sort per (r,h) (:641-663)
+            for (uint32_t h = 0; h < num_walks; ++h) {
+                grp.clear();
+                for (int32_t i = 0; i < n; ++i) if (raw[b + order[i]].h == (int32_t)h) grp.push_back(order[i]);
+                if (grp.empty()) continue;
+                const auto &ix = kmer_index[h];
+                std::sort(grp.begin(), grp.end(), [&](int32_t x, int32_t y) {
+                    const uint32_t mx = raw[b + x].m, my = raw[b + y].m;
+                    const int32_t ax0 = ix.v[ix.voff[mx]], ay0 = ix.v[ix.voff[my]];
+                    if (ax0 != ay0) return ax0 < ay0;
+                    return ix.v[ix.voff[mx + 1] - 1] < ix.v[ix.voff[my + 1] - 1];
+                });
+                for (int32_t x : grp) {
+                    const uint32_t m = raw[b + x].m;
+                    Occ o{r, (int32_t)h, (uint32_t)vpool_l.size(), ix.voff[m + 1] - ix.voff[m]};
+                    vpool_l.insert(vpool_l.end(), ix.v.begin() + ix.voff[m], ix.v.begin() + ix.voff[m + 1]);
+                    occs_l.push_back(o);
+                }
+            }
+        }
+    }
+    {
+        size_t no = 0, nv = 0;
+        for (int c = 0; c < n_chunks; ++c) { no += occs_c[c].size(); nv += vpool_c[c].size(); }
+        occs.reserve(no); vpool.reserve(nv);
+        for (int c = 0; c < n_chunks; ++c) {
+            const uint32_t base = (uint32_t)vpool.size();
+            vpool.insert(vpool.end(), vpool_c[c].begin(), vpool_c[c].end());
+            for (Occ o : occs_c[c]) { o.off += base; occs.push_back(o); }
         }
     }
     sum.anchors_per_hap.assign(num_walks, 0);
@@ -321,158 +349,180 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
 }
 
 // ======================================================================================
-// ExpandedGraph  (ExpandedGraph.hpp:29-102, 269-409)
+// ExpandedGraph  (ExpandedGraph.hpp:29-102, 269-409), flat CSR restatement
 // ======================================================================================
-void ExpandedGraph::topologically_reorder(int sink) {
-    const std::size_t n = adj_list.size();
-    std::vector<int> indeg(n, 0);
-    for (auto &nbrs : adj_list) for (auto &vw : nbrs) ++indeg[vw.first];
-    std::queue<int> q;
-    for (std::size_t v = 0; v < n; ++v) if (indeg[v] == 0 && (int)v != sink) q.push((int)v);
-    bool sink_ready = (indeg[sink] == 0);
-    std::vector<int> order;
-    order.reserve(n);
-    while (!q.empty() || sink_ready) {
-        int u;
-        if (!q.empty()) { u = q.front(); q.pop(); }
-        else { u = sink; sink_ready = false; }
-        order.push_back(u);
-        for (auto &vw : adj_list[u])
-            if (--indeg[vw.first] == 0) { if (vw.first == sink) sink_ready = true; else q.push(vw.first); }
+void ExpandedGraph::permute(const std::vector<int32_t> &order) {
+    // new vertex i = old vertex order[i]; adjacency keeps its per-vertex order (ExpandedGraph.hpp:93-101, 392-400)
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char *w) { if (dbg) { double t = now_s(); fprintf(stderr, "[dg::permute] %-18s %.3f s\n", w, t - tl); tl = t; } };
+    const int32_t nn = (int32_t)order.size();
+    std::vector<int32_t> new_idx(nn);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nn; ++i) new_idx[order[i]] = i;
+    std::vector<int64_t> noff((size_t)nn + 1, 0);
+    for (int32_t i = 0; i < nn; ++i) noff[i + 1] = noff[i] + deg(order[i]);
+    lap("new_idx+noff");
+    std::vector<int32_t> ndst(adj_dst.size());
+    std::vector<uint8_t> nw(adj_w.size());
+    lap("alloc");
+    // the remap is a random gather (cache-miss bound): spread it over the host threads
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nn; ++i) {
+        int64_t o = noff[i];
+        for (int64_t e = adj_off[order[i]]; e < adj_off[order[i] + 1]; ++e, ++o) { ndst[o] = new_idx[adj_dst[e]]; nw[o] = adj_w[e]; }
     }
-    if (order.size() != n) throw std::runtime_error("Graph contains a cycle; topological order impossible");
-    std::vector<int> new_idx(n);
-    for (std::size_t i = 0; i < n; ++i) new_idx[order[i]] = (int)i;
-    std::vector<std::vector<int>> new_color(n), new_orig(n);
-    std::vector<int> new_hap(n);
-    for (std::size_t i = 0; i < n; ++i) {
-        new_color[i] = std::move(color[order[i]]);
-        new_orig[i] = std::move(original_vertex[order[i]]);
-        new_hap[i] = haplotype[order[i]];
+    lap("edges");
+    adj_off.swap(noff); adj_dst.swap(ndst); adj_w.swap(nw);
+    std::vector<int32_t> nh(nn);
+    std::vector<uint32_t> noo(nn), nol(nn);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nn; ++i) { nh[i] = haplotype[order[i]]; noo[i] = orig_off[order[i]]; nol[i] = orig_len[order[i]]; }
+    haplotype.swap(nh); orig_off.swap(noo); orig_len.swap(nol);
+    if ((int32_t)level.size() == nn) {
+        std::vector<int32_t> nl(nn);
+        for (int32_t i = 0; i < nn; ++i) nl[i] = level[order[i]];
+        level.swap(nl);
     }
-    color.swap(new_color); original_vertex.swap(new_orig); haplotype.swap(new_hap);
-    std::vector<std::vector<std::pair<int, int>>> new_adj(n);
-    for (std::size_t old_u = 0; old_u < n; ++old_u) {
-        int u = new_idx[old_u];
-        new_adj[u].reserve(adj_list[old_u].size());
-        for (auto &vw : adj_list[old_u]) new_adj[u].emplace_back(new_idx[vw.first], vw.second);
-    }
-    adj_list.swap(new_adj);
+    lap("vertex arrays");
+    std::vector<int64_t> nco((size_t)nn + 1, 0);
+    for (int32_t i = 0; i < nn; ++i) nco[i + 1] = nco[i] + ncol(order[i]);
+    std::vector<int32_t> ncp(col_pool.size());
+    for (int32_t i = 0; i < nn; ++i)
+        std::copy(col_pool.begin() + col_off[order[i]], col_pool.begin() + col_off[order[i] + 1], ncp.begin() + nco[i]);
+    col_off.swap(nco); col_pool.swap(ncp);
+    lap("colours");
 }
 
-int ExpandedGraph::strict_bfs_levelize_and_reorder() {
-    const std::size_t n = adj_list.size();
-    std::vector<int> indeg(n, 0), outdeg(n, 0);
-    for (std::size_t u = 0; u < n; ++u) {
-        outdeg[u] = (int)adj_list[u].size();
-        for (const auto &vw : adj_list[u]) ++indeg[vw.first];
+void ExpandedGraph::topologically_reorder(int sink) {                  // ExpandedGraph.hpp:29-102
+    std::vector<int32_t> indeg(n, 0);
+    for (int32_t d : adj_dst) ++indeg[d];
+    std::vector<int32_t> order;                                        // doubles as the FIFO queue
+    order.reserve(n);
+    for (int32_t v = 0; v < n; ++v) if (indeg[v] == 0 && v != sink) order.push_back(v);   // never push the sink now
+    bool sink_ready = (indeg[sink] == 0);
+    size_t head = 0;
+    while (head < order.size() || sink_ready) {
+        int u;
+        if (head < order.size()) u = order[head++];                    // process the queue first
+        else { u = sink; sink_ready = false; order.push_back(sink); ++head; }   // queue empty -> only the sink is left
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) {
+            const int v = adj_dst[e];
+            if (--indeg[v] == 0) { if (v == sink) sink_ready = true; else order.push_back(v); }
+        }
     }
+    if ((int32_t)order.size() != n) throw std::runtime_error("Graph contains a cycle; topological order impossible");
+    permute(order);
+}
+
+int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // ExpandedGraph.hpp:269-409
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char *w) { if (dbg) { double t = now_s(); fprintf(stderr, "[dg::levelize] %-18s %.3f s\n", w, t - tl); tl = t; } };
+    const int32_t n0 = n;
+    if (n0 == 0) return 0;
+    std::vector<int32_t> indeg(n0, 0);
+    for (int32_t d : adj_dst) ++indeg[d];
     int source = -1;
-    for (std::size_t v = 0; v < n; ++v)
-        if (indeg[v] == 0 && outdeg[v] > 0) {
-            if (source == -1) source = (int)v;
+    for (int32_t v = 0; v < n0; ++v)
+        if (indeg[v] == 0 && deg(v) > 0) {
+            if (source == -1) source = v;
             else { std::cout << "Uh oh, multiple potential sources found while leveling\n"; std::exit(-1); }
         }
-    const int n0 = (int)adj_list.size();
-    if (n0 == 0) return 0;
     if (source < 0 || source >= n0) throw std::runtime_error("bad source index");
-
-    std::vector<int> dist(n0, -1);                                     // 1) BFS
-    {
-        std::queue<int> q;
-        dist[source] = 0; q.push(source);
-        while (!q.empty()) {
-            int u = q.front(); q.pop();
-            for (auto &vw : adj_list[u]) if (dist[vw.first] == -1) { dist[vw.first] = dist[u] + 1; q.push(vw.first); }
-        }
+    std::vector<int32_t> dist(n0, -1), q;                              // 1) BFS from the source
+    q.reserve(n0);
+    dist[source] = 0; q.push_back(source);
+    for (size_t h = 0; h < q.size(); ++h) {
+        const int u = q[h];
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (dist[v] == -1) { dist[v] = dist[u] + 1; q.push_back(v); } }
     }
-    std::vector<int> topo;                                             // 2) Kahn over ALL indeg-0 vertices
+    lap("indeg+bfs");
+    std::vector<int32_t> topo;                                         // 2) Kahn over ALL indeg-0 vertices
     topo.reserve(n0);
-    {
-        std::queue<int> qk;
-        for (int v = 0; v < n0; ++v) if (indeg[v] == 0) qk.push(v);
-        while (!qk.empty()) {
-            int u = qk.front(); qk.pop();
-            topo.push_back(u);
-            for (auto &vw : adj_list[u]) if (--indeg[vw.first] == 0) qk.push(vw.first);
-        }
+    for (int32_t v = 0; v < n0; ++v) if (indeg[v] == 0) topo.push_back(v);
+    for (size_t h = 0; h < topo.size(); ++h) {
+        const int u = topo[h];
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) if (--indeg[adj_dst[e]] == 0) topo.push_back(adj_dst[e]);
     }
-    if ((int)topo.size() != n0) throw std::runtime_error("Graph contains a cycle; strict leveling requires a DAG");
-    std::vector<int> lvl(n0, 0);                                       // 3) seed / relax
-    for (int v = 0; v < n0; ++v) if (dist[v] >= 0) lvl[v] = dist[v];
-    for (int u : topo) for (auto &vw : adj_list[u]) if (lvl[vw.first] <= lvl[u]) lvl[vw.first] = lvl[u] + 1;
+    if ((int32_t)topo.size() != n0) throw std::runtime_error("Graph contains a cycle; strict leveling requires a DAG");
+    std::vector<int32_t> lvl(n0, 0);                                   // 3) seed / relax
+    for (int32_t v = 0; v < n0; ++v) if (dist[v] >= 0) lvl[v] = dist[v];
+    for (int u : topo) for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (lvl[v] <= lvl[u]) lvl[v] = lvl[u] + 1; }
 
-    // 4) dummies for skipped levels
-    std::vector<std::vector<std::pair<int, int>>> next_adj(n0);
-    std::vector<std::vector<int>> next_color = std::move(color);
-    std::vector<std::vector<int>> next_orig = std::move(original_vertex);
-    std::vector<int> next_lvl = lvl;
-    std::vector<int> next_hap = haplotype;
-    for (int u = 0; u < n0; ++u) {
-        for (auto &vw : adj_list[u]) {
-            const int v = vw.first, w = vw.second;
-            int gap = next_lvl[v] - next_lvl[u] - 1;
-            if (gap <= 0) {
-                next_adj[u].emplace_back(v, w);
-            } else {
-                int prev = u;
-                for (int step = 1; step <= gap; ++step) {
-                    int dummy = (int)next_adj.size();                  // add_dummy (:326-334)
-                    next_adj.emplace_back();
-                    next_color.emplace_back();
-                    next_orig.emplace_back(next_orig[u]);
-                    next_lvl.push_back(next_lvl[u] + step);
-                    next_hap.push_back(haplotype[u]);
-                    next_adj[prev].emplace_back(dummy, (step == 1 ? w : 0));
-                    prev = dummy;
-                }
-                next_adj[prev].emplace_back(v, 0);
+    lap("kahn+relax");
+    // 4) dummies for skipped levels: edge (u,v,w) with gap g becomes u -w-> d1 -0-> ... -0-> dg -0-> v; dummy ids are
+    //    handed out in (u ascending, edge order) sequence (prefix sum, so vertices can be processed in parallel), each
+    //    inherits haplotype[u] and u's original-vertex list.
+    std::vector<int64_t> dbase((size_t)n0 + 1, 0);                     // dummies created before vertex u's edges
+#pragma omp parallel for schedule(static)
+    for (int32_t u = 0; u < n0; ++u) {
+        int64_t c = 0;
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int gap = lvl[adj_dst[e]] - lvl[u] - 1; if (gap > 0) c += gap; }
+        dbase[u + 1] = c;
+    }
+    for (int32_t u = 0; u < n0; ++u) dbase[u + 1] += dbase[u];
+    const int64_t n_dummy = dbase[n0];
+    const int64_t n1l = (int64_t)n0 + n_dummy;
+    if (n1l >= INT32_MAX) throw std::runtime_error("expanded graph too large");
+    const int32_t n1 = (int32_t)n1l;
+    std::vector<int32_t> lv(n1), hp2(n1);
+    std::vector<uint32_t> oo(n1), ol(n1);
+    std::vector<int64_t> noff((size_t)n1 + 1, 0);
+    std::vector<int32_t> ndst((size_t)adj_dst.size() + (size_t)n_dummy);
+    std::vector<uint8_t> nw(ndst.size());
+    // old vertices keep their out-degree and edge slots; dummy d (id n0 + d) owns the single slot E + d
+    const int64_t E0 = (int64_t)adj_dst.size();
+#pragma omp parallel for schedule(static)
+    for (int32_t u = 0; u <= n0; ++u) noff[u] = adj_off[u];
+#pragma omp parallel for schedule(static)
+    for (int32_t d = n0 + 1; d <= n1; ++d) noff[d] = E0 + (d - n0);
+#pragma omp parallel for schedule(static)
+    for (int32_t u = 0; u < n0; ++u) {
+        lv[u] = lvl[u]; hp2[u] = haplotype[u]; oo[u] = orig_off[u]; ol[u] = orig_len[u];
+        int32_t next_dummy = n0 + (int32_t)dbase[u];
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) {
+            const int v = adj_dst[e], w = adj_w[e];
+            const int gap = lvl[v] - lvl[u] - 1;
+            if (gap <= 0) { ndst[e] = v; nw[e] = (uint8_t)w; continue; }
+            int64_t slot = e;                                           // where the next hop is written
+            for (int step = 1; step <= gap; ++step) {
+                const int32_t dmy = next_dummy++;
+                lv[dmy] = lvl[u] + step; hp2[dmy] = haplotype[u]; oo[dmy] = orig_off[u]; ol[dmy] = orig_len[u];
+                ndst[slot] = dmy; nw[slot] = (uint8_t)(step == 1 ? w : 0);
+                slot = E0 + (dmy - n0);
             }
+            ndst[slot] = v; nw[slot] = 0;
         }
     }
-    adj_list.swap(next_adj);
-    color.swap(next_color);
-    original_vertex.swap(next_orig);
-    level.swap(next_lvl);
-    haplotype.swap(next_hap);
+    adj_off.swap(noff); adj_dst.swap(ndst); adj_w.swap(nw);
+    haplotype.swap(hp2); orig_off.swap(oo); orig_len.swap(ol); level.swap(lv);
+    {
+        std::vector<int64_t> nco((size_t)n1 + 1);                      // dummies have no colour
+        for (int32_t v = 0; v <= n0; ++v) nco[v] = col_off[v];
+        for (int32_t v = n0 + 1; v <= n1; ++v) nco[v] = col_off[n0];
+        col_off.swap(nco);
+    }
+    n = n1;
 
-    // 5) order by (level, id)
-    const int n1 = (int)adj_list.size();
+    lap("dummies");
+    // 5) order by (level, id): stable, so a counting sort by level
     int max_level = 0;
-    for (int v = 0; v < n1; ++v) if (level[v] > max_level) max_level = level[v];
-    std::vector<int> width(max_level + 1, 0);
-    for (int v = 0; v < n1; ++v) ++width[level[v]];
+    for (int32_t v = 0; v < n1; ++v) if (level[v] > max_level) max_level = level[v];
+    std::vector<int32_t> width(max_level + 1, 0);
+    for (int32_t v = 0; v < n1; ++v) ++width[level[v]];
     int max_width = 0;
     for (int w : width) if (w > max_width) max_width = w;
-    // stable sort by (level, id) over ids 0..n1-1 == counting sort by level
-    std::vector<int> start(max_level + 2, 0);
-    for (int l = 0; l <= max_level; ++l) start[l + 1] = start[l] + width[l];
-    std::vector<int> order(n1), new_id(n1, -1);
+    level_off.assign(max_level + 2, 0);
+    for (int l = 0; l <= max_level; ++l) level_off[l + 1] = level_off[l] + width[l];
+    std::vector<int32_t> order(n1);
     {
-        std::vector<int> fill(start.begin(), start.end() - 1);
-        for (int v = 0; v < n1; ++v) order[fill[level[v]]++] = v;
+        std::vector<int32_t> fill(level_off.begin(), level_off.end() - 1);
+        for (int32_t v = 0; v < n1; ++v) order[fill[level[v]]++] = v;
     }
-    for (int i = 0; i < n1; ++i) new_id[order[i]] = i;
-    std::vector<std::vector<int>> new_color(n1), new_orig(n1);
-    std::vector<int> new_level(n1), new_hap(n1);
-    for (int i = 0; i < n1; ++i) {
-        int old = order[i];
-        new_color[i] = std::move(color[old]);
-        new_orig[i] = std::move(original_vertex[old]);
-        new_level[i] = level[old];
-        new_hap[i] = haplotype[old];
-    }
-    color.swap(new_color); original_vertex.swap(new_orig); level.swap(new_level); haplotype.swap(new_hap);
-    std::vector<std::vector<std::pair<int, int>>> new_adj(n1);
-    for (int old_u = 0; old_u < n1; ++old_u) {
-        int u = new_id[old_u];
-        new_adj[u].reserve(adj_list[old_u].size());
-        for (auto &vw : adj_list[old_u]) new_adj[u].emplace_back(new_id[vw.first], vw.second);
-    }
-    adj_list.swap(new_adj);
-    vertices_in_level.clear();
-    vertices_in_level.resize(max_level + 1);
-    for (int u = 0; u < n1; ++u) vertices_in_level[level[u]].push_back(u);
+    lap("sort");
+    permute(order);
+    lap("permute");
     return max_width;
 }
 
@@ -531,17 +581,18 @@ bool DpGraphStorage::load(const std::string &path, int &R) {
 // haploid DP  (approximator.cpp:44-168) -- CPU by design
 // ======================================================================================
 std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
-    int n = (int)g.adj_list.size();
+    int n = g.n;
     const std::size_t N = (std::size_t)n * (R + 1);
     std::vector<int> dp(N, 0), back_vtx(N, -1), back_r(N, -1);         // :50-52 (0, not -inf: quirk kept)
     auto idx = [&](int v, int r) -> std::size_t { return std::size_t(v) * (R + 1) + r; };
     for (int u = 0; u < n; u++)
         for (int r = 0; r <= R; r++)
-            for (auto &vw : g.adj_list[u]) {
-                const int v = vw.first, w_uv = vw.second;
+            for (int64_t e = g.adj_off[u]; e < g.adj_off[u + 1]; ++e) {
+                const int v = g.adj_dst[e], w_uv = g.adj_w[e];
+                const std::size_t csz = (std::size_t)g.ncol(v);
                 // NB the reference compares in size_t (int + size_t > int): :60
-                if (r + w_uv <= R && (std::size_t)dp[idx(u, r)] + g.color[v].size() > (std::size_t)dp[idx(v, r + w_uv)]) {
-                    dp[idx(v, r + w_uv)] = dp[idx(u, r)] + (int)g.color[v].size();
+                if (r + w_uv <= R && (std::size_t)dp[idx(u, r)] + csz > (std::size_t)dp[idx(v, r + w_uv)]) {
+                    dp[idx(v, r + w_uv)] = dp[idx(u, r)] + (int)csz;
                     back_vtx[idx(v, r + w_uv)] = u;
                     back_r[idx(v, r + w_uv)] = r;
                 }
@@ -553,7 +604,7 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
         std::map<int, int> occ_count;
         int cur_vtx = n - 1, cur_r = r;
         while (cur_vtx != -1) {
-            for (auto c : g.color[cur_vtx]) { true_colours.insert(c); occ_count[c] += 1; }
+            for (int64_t q = g.col_off[cur_vtx]; q < g.col_off[cur_vtx + 1]; ++q) { true_colours.insert(g.col_pool[q]); occ_count[g.col_pool[q]] += 1; }
             int temp_vtx = cur_vtx;
             cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
             cur_r = back_r[idx(temp_vtx, cur_r)];
@@ -597,8 +648,10 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
     std::vector<int> out;
     std::unordered_set<int> seen;                                      // remove_duplicates (:30-40)
     for (auto u : path)
-        for (auto uo : g.original_vertex[u])
+        for (uint32_t q = 0; q < g.orig_len[u]; ++q) {
+            const int uo = g.orig_pool[g.orig_off[u] + q];
             if (seen.insert(uo).second) out.push_back(uo);
+        }
     return out;
 }
 
@@ -609,73 +662,99 @@ int Pipeline::solve(std::string &err) {
     double t0 = now_s();
     int32_t number_of_vertices = 0;
     for (size_t h = 0; h < paths.size(); h++) number_of_vertices += (int32_t)paths[h].size();
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> adj(2 + number_of_vertices);
-    std::vector<std::vector<int32_t>> v2e(n_vtx, std::vector<int32_t>(paths.size(), -1));
-    std::vector<std::vector<int32_t>> e2o(2 + number_of_vertices);
-    std::vector<int32_t> e2h(2 + number_of_vertices);
+    const int H = (int)paths.size();
+    // Adjacency is recorded as one global push log; a stable counting sort by source gives the CSR with the
+    // reference's per-vertex push order (chain edge, weight-1 edges, start->super edges, overlap edges).
+    struct ELog { int32_t src, dst; uint8_t w; };
+    std::vector<ELog> elog;
+    elog.reserve((size_t)number_of_vertices * 2 + 1024);
+    ExpandedGraph g;
+    int32_t nvert = 2 + number_of_vertices;                            // :1022
+    g.haplotype.assign(nvert, 0);                                      // :1025 (source and sink keep 0)
+    g.orig_off.assign(nvert, 0);
+    g.orig_len.assign(nvert, 0);
+    g.orig_pool.reserve((size_t)number_of_vertices + vpool.size());
+    std::vector<int32_t> v2e((size_t)n_vtx * H, -1);                   // vertex_to_expanded_map[v][h]  (:1023)
 
-    const int sink = (int)adj.size() - 1;
+    const int sink = nvert - 1;
     int32_t current_vertex = 1;
-    for (size_t h = 0; h < paths.size(); h++) {                        // :1029-1049
-        adj[0].push_back({current_vertex, 0});
+    for (int h = 0; h < H; h++) {                                      // :1029-1049
+        elog.push_back({0, current_vertex, 0});
         for (size_t i = 0; i < paths[h].size(); i++) {
-            v2e[paths[h][i]][h] = current_vertex;
-            e2o[current_vertex].push_back((int32_t)paths[h][i]);
-            e2h[current_vertex] = (int32_t)h;
-            if (i < paths[h].size() - 1) adj[current_vertex].push_back({current_vertex + 1, 0});
-            else adj[current_vertex].push_back({(int32_t)sink, 0});
+            v2e[(size_t)paths[h][i] * H + h] = current_vertex;         // last occurrence wins (:1035)
+            g.orig_off[current_vertex] = (uint32_t)g.orig_pool.size();
+            g.orig_len[current_vertex] = 1;
+            g.orig_pool.push_back((int32_t)paths[h][i]);
+            g.haplotype[current_vertex] = h;
+            if (i < paths[h].size() - 1) elog.push_back({current_vertex, current_vertex + 1, 0});
+            else elog.push_back({current_vertex, sink, 0});
             current_vertex++;
         }
     }
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char *w) { if (dbg) { double t = now_s(); fprintf(stderr, "[dg::build] %-18s %.3f s\n", w, t - tl); tl = t; } };
+    lap("chains");
     // recombination edges (:1051-1095)
-    std::vector<std::vector<int>> vertex_w_uv(n_vtx);
-    for (size_t u = 0; u < adj_list.size(); u++) vertex_w_uv[u] = std::vector<int>(adj_list[u].size(), -1);
-    current_vertex = (int32_t)adj.size();
-    for (size_t h = 0; h < paths.size(); h++) {
+    std::vector<int64_t> wslot_off((size_t)n_vtx + 1, 0);              // vertex_w_uv[u][j] flattened
+    for (size_t u = 0; u < adj_list.size(); u++) wslot_off[u + 1] = wslot_off[u] + (int64_t)adj_list[u].size();
+    std::vector<int32_t> vertex_w_uv((size_t)wslot_off[n_vtx], -1);
+    std::vector<uint8_t> w_filled;                                     // "adjacency of w_uv is non-empty" (:1082)
+    for (int h = 0; h < H; h++) {
         for (size_t i = 0; i < paths[h].size(); i++) {
-            int u = (int)paths[h][i];
+            const int u = (int)paths[h][i];
             for (size_t j = 0; j < adj_list[u].size(); j++) {
-                int v = (int)adj_list[u][j];
+                const int v = (int)adj_list[u][j];
                 if (i == paths[h].size() - 1 || v != (int)paths[h][i + 1]) {
-                    if (vertex_w_uv[u][j] == -1) {
-                        adj.emplace_back();
-                        e2o.emplace_back();
-                        e2h.push_back(-1);
-                        vertex_w_uv[u][j] = current_vertex;
-                        current_vertex++;
+                    int32_t &wv = vertex_w_uv[wslot_off[u] + (int64_t)j];
+                    if (wv == -1) {
+                        wv = nvert++;
+                        g.haplotype.push_back(-1);
+                        g.orig_off.push_back(0);
+                        g.orig_len.push_back(0);
+                        w_filled.push_back(0);
                     }
-                    adj[v2e[u][h]].push_back({vertex_w_uv[u][j], 1});
-                    if (adj[vertex_w_uv[u][j]].empty())
-                        for (auto v_e : v2e[v]) if (v_e >= 0) adj[vertex_w_uv[u][j]].push_back({v_e, 0});
+                    elog.push_back({v2e[(size_t)u * H + h], wv, 1});
+                    uint8_t &filled = w_filled[wv - (number_of_vertices + 2)];
+                    if (!filled)
+                        for (int hh = 0; hh < H; ++hh) {
+                            const int32_t v_e = v2e[(size_t)v * H + hh];
+                            if (v_e >= 0) { elog.push_back({wv, v_e, 0}); filled = 1; }
+                        }
                 }
             }
         }
     }
+    { std::vector<int32_t>().swap(vertex_w_uv); }
 
+    lap("recomb edges");
     // anchors -> AnchorRec per haplotype (:1114-1176)
-    std::vector<std::vector<int32_t>> color(adj.size());
     std::vector<std::vector<AnchorRec>> anchorsByHap(paths.size());
     std::vector<int32_t> color_to_anchor;
-    int nextID = (int)adj.size();
+    int nextID = nvert;
     int colourID = 0;
     {
+        std::vector<size_t> cnt(H, 0);
+        for (const Occ &o : occs) cnt[o.h]++;
+        for (int h = 0; h < H; ++h) anchorsByHap[h].reserve(cnt[h]);
         size_t p = 0;
         while (p < occs.size()) {                                      // ids without occurrences use no colour
             const int32_t a = occs[p].a;
             for (; p < occs.size() && occs[p].a == a; ++p) {           // occs sorted by (a, h, occurrence order)
                 const Occ &o = occs[p];
                 const int h = o.h;
-                int startOrig = vpool[o.off], endOrig = vpool[o.off + o.len - 1];
-                int startExp = v2e[startOrig][h], endExp = v2e[endOrig][h];
+                const int startOrig = vpool[o.off], endOrig = vpool[o.off + o.len - 1];
+                const int startExp = v2e[(size_t)startOrig * H + h], endExp = v2e[(size_t)endOrig * H + h];
                 int nodeID;
                 if (startExp == endExp) {
                     nodeID = startExp;
                 } else {
-                    adj[startExp].push_back({nextID, 0});
-                    adj.push_back({{endExp, 0}});
-                    e2o.emplace_back(vpool.begin() + o.off, vpool.begin() + o.off + o.len);
-                    color.push_back({});
-                    e2h.push_back(-1);
+                    elog.push_back({startExp, nextID, 0});             // :1148
+                    elog.push_back({nextID, endExp, 0});               // :1149
+                    g.orig_off.push_back((uint32_t)g.orig_pool.size());
+                    g.orig_len.push_back(o.len);
+                    g.orig_pool.insert(g.orig_pool.end(), vpool.begin() + o.off, vpool.begin() + o.off + o.len);
+                    g.haplotype.push_back(-1);
                     nodeID = nextID++;
                 }
                 anchorsByHap[h].push_back({startOrig, endOrig, startExp, endExp, {colourID}, nodeID});
@@ -684,11 +763,20 @@ int Pipeline::solve(std::string &err) {
             colourID++;
         }
     }
+    nvert = nextID;
     const int n_colours = colourID;
     sum.n_colours = n_colours;
+    { std::vector<int32_t>().swap(v2e); }
 
+    lap("anchor recs");
     // per-haplotype sweep: overlap edges + containment colour propagation (:1193-1246)
-    for (size_t h = 0; h < paths.size(); ++h) {
+    // Haplotypes are independent here (anchor records, node ids and stacks are per haplotype); the overlap edges
+    // each one produces are appended to the push log afterwards in haplotype order, as the serial loop would.
+    std::vector<std::vector<ELog>> ov_edges(paths.size());
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> colpairs_h(paths.size());   // (nodeID, colour)
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t hh = 0; hh < (int64_t)paths.size(); ++hh) {
+        const size_t h = (size_t)hh;
         auto &vec = anchorsByHap[h];
         if (vec.empty()) continue;
         std::sort(vec.begin(), vec.end(), [](const AnchorRec &a, const AnchorRec &b) {
@@ -699,7 +787,7 @@ int Pipeline::solve(std::string &err) {
         for (auto &anc : vec) {
             while (!stk.empty() && stk.back()->endExp < anc.startExp) stk.pop_back();
             if (!stk.empty() && anc.startExp <= stk.back()->endExp && stk.back()->nodeID != anc.nodeID)
-                adj[stk.back()->nodeID].push_back({anc.nodeID, 0});
+                ov_edges[h].push_back({stk.back()->nodeID, anc.nodeID, 0});
             for (int i = (int)stk.size() - 1; i >= 0; --i) {
                 if (anc.endExp <= stk[i]->endExp) {
                     for (int c : anc.colours)
@@ -709,27 +797,50 @@ int Pipeline::solve(std::string &err) {
             }
             stk.push_back(&anc);
         }
-        for (const auto &anc : vec) {
-            auto &dst = color[anc.nodeID];
-            dst.insert(dst.end(), anc.colours.begin(), anc.colours.end());
-            std::sort(dst.begin(), dst.end());
-            dst.erase(std::unique(dst.begin(), dst.end()), dst.end());
-        }
+        auto &cp = colpairs_h[h];
+        for (const auto &anc : vec)                                    // :1240-1245: per node, sorted-unique union
+            for (int c : anc.colours) cp.emplace_back(anc.nodeID, c);
+        std::sort(cp.begin(), cp.end());
+        cp.erase(std::unique(cp.begin(), cp.end()), cp.end());
     }
-    { std::vector<std::vector<int32_t>>().swap(v2e); }
+    lap("sweep");
+    for (auto &ve : ov_edges) elog.insert(elog.end(), ve.begin(), ve.end());
+    { std::vector<std::vector<ELog>>().swap(ov_edges); }
+    // node ids of different haplotypes are disjoint, so the per-haplotype sorted lists only need a count + scatter
+    std::vector<std::pair<int32_t, int32_t>> colpairs;
+    {
+        size_t tot = 0;
+        for (auto &cp : colpairs_h) tot += cp.size();
+        colpairs.reserve(tot);
+        for (auto &cp : colpairs_h) colpairs.insert(colpairs.end(), cp.begin(), cp.end());
+    }
+    { std::vector<std::vector<std::pair<int32_t, int32_t>>>().swap(colpairs_h); }
 
-    ExpandedGraph g;                                                   // :1249-1256
-    g.adj_list.resize(adj.size());
-    for (size_t u = 0; u < adj.size(); ++u) { g.adj_list[u].assign(adj[u].begin(), adj[u].end()); }
-    { std::vector<std::vector<std::pair<int32_t, int32_t>>>().swap(adj); }
-    g.color.resize(color.size());
-    for (size_t u = 0; u < color.size(); ++u) g.color[u].assign(color[u].begin(), color[u].end());
-    g.original_vertex.resize(e2o.size());
-    for (size_t u = 0; u < e2o.size(); ++u) g.original_vertex[u].assign(e2o[u].begin(), e2o[u].end());
-    g.haplotype.assign(e2h.begin(), e2h.end());
+    // assemble the flat graph
+    g.n = nvert;
+    g.adj_off.assign((size_t)nvert + 1, 0);
+    for (const ELog &e : elog) g.adj_off[e.src + 1]++;
+    for (int32_t v = 0; v < nvert; ++v) g.adj_off[v + 1] += g.adj_off[v];
+    g.adj_dst.resize(elog.size());
+    g.adj_w.resize(elog.size());
+    {
+        std::vector<int64_t> fill(g.adj_off.begin(), g.adj_off.end() - 1);
+        for (const ELog &e : elog) { const int64_t o = fill[e.src]++; g.adj_dst[o] = e.dst; g.adj_w[o] = e.w; }
+    }
+    { std::vector<ELog>().swap(elog); }
+    g.col_off.assign((size_t)nvert + 1, 0);
+    for (auto &pc : colpairs) g.col_off[pc.first + 1]++;
+    for (int32_t v = 0; v < nvert; ++v) g.col_off[v + 1] += g.col_off[v];
+    g.col_pool.resize(colpairs.size());
+    {
+        std::vector<int64_t> fill(g.col_off.begin(), g.col_off.end() - 1);
+        for (auto &pc : colpairs) g.col_pool[fill[pc.first]++] = pc.second;   // a node's colours arrive ascending
+    }
+    { std::vector<std::pair<int32_t, int32_t>>().swap(colpairs); }
+    lap("assemble");
     stamp("expanded_graph_build", t0);
     t0 = now_s();
-    g.topologically_reorder(sink);
+    g.topologically_reorder(sink);                                     // :1256
     stamp("topologically_reorder", t0);
 
     if (opt.ploidy == 1) {                                             // :1260-1278
@@ -762,32 +873,25 @@ int Pipeline::solve(std::string &err) {
 int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
                       const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err) {
     double t0 = now_s();
-    const int L = (int)g.vertices_in_level.size();
-    const int nV = (int)g.adj_list.size();
-    if (!opt.quiet && g.vertices_in_level[0].size() > 1) std::cout << "There is more than one source on level zero!" << std::endl;
-    // flatten (vertex ids are level-sorted: ExpandedGraph.hpp:360-407)
+    const int L = (int)g.level_off.size() - 1;
+    const int nV = g.n;
+    if (!opt.quiet && g.level_off[1] - g.level_off[0] > 1) std::cout << "There is more than one source on level zero!" << std::endl;
+    // the flat graph already is the dg_dp_graph layout (vertex ids are level-sorted: ExpandedGraph.hpp:360-407)
     dpg = DpGraphStorage();
-    dpg.level_off.resize(L + 1);
-    dpg.level_off[0] = 0;
-    for (int l = 0; l < L; ++l) dpg.level_off[l + 1] = dpg.level_off[l] + (int32_t)g.vertices_in_level[l].size();
-    dpg.out_off.assign(nV + 1, 0);
-    for (int v = 0; v < nV; ++v) dpg.out_off[v + 1] = dpg.out_off[v] + (int64_t)g.adj_list[v].size();
-    dpg.out_dst.resize(dpg.out_off[nV]);
-    dpg.out_w.resize(dpg.out_off[nV]);
-    for (int v = 0; v < nV; ++v) {
-        int64_t o = dpg.out_off[v];
-        for (auto &vw : g.adj_list[v]) { dpg.out_dst[o] = vw.first; dpg.out_w[o] = (uint8_t)vw.second; ++o; }
-    }
-    dpg.hom_off.assign(nV + 1, 0);
-    dpg.het_off.assign(nV + 1, 0);
+    dpg.level_off = g.level_off;
+    dpg.out_off = g.adj_off;
+    dpg.out_dst = g.adj_dst;
+    dpg.out_w = g.adj_w;
+    dpg.hom_off.assign((size_t)nV + 1, 0);
+    dpg.het_off.assign((size_t)nV + 1, 0);
     if (!opt.quiet) std::cout << "Creating hetro/hom-zygous colors per vertex lists" << std::endl;
-    for (int v = 0; v < nV; ++v) {                                     // :431-453 (colour lists are already sorted-unique)
-        std::vector<int> H, T;
-        for (int c : g.color[v]) { if (color_homo_bv.at(c) == 1) H.push_back(c); else T.push_back(c); }
-        std::sort(H.begin(), H.end()); H.erase(std::unique(H.begin(), H.end()), H.end());
-        std::sort(T.begin(), T.end()); T.erase(std::unique(T.begin(), T.end()), T.end());
-        dpg.hom_col.insert(dpg.hom_col.end(), H.begin(), H.end());
-        dpg.het_col.insert(dpg.het_col.end(), T.begin(), T.end());
+    dpg.hom_col.reserve(g.col_pool.size());
+    dpg.het_col.reserve(g.col_pool.size());
+    for (int v = 0; v < nV; ++v) {                                     // :431-453 (lists are sorted-unique already)
+        for (int64_t q = g.col_off[v]; q < g.col_off[v + 1]; ++q) {
+            const int c = g.col_pool[q];
+            if (color_homo_bv.at(c) == 1) dpg.hom_col.push_back(c); else dpg.het_col.push_back(c);
+        }
         dpg.hom_off[v + 1] = (int64_t)dpg.hom_col.size();
         dpg.het_off[v + 1] = (int64_t)dpg.het_col.size();
     }
@@ -820,17 +924,18 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     const int r1 = (int)wp1.size() - 1, r2 = (int)wp2.size() - 1;              // :784-785
 
     auto find_next_zero_hap = [&](int src, int target_hap) -> int {          // :732-755
-        if (g.haplotype.at(src) == target_hap && g.original_vertex.at(src).size() > 0) return src;
+        if (g.haplotype.at(src) == target_hap && g.orig_len.at(src) > 0) return src;
         std::queue<int> q;
         std::unordered_set<int> visited;
         q.push(src); visited.insert(src);
         while (!q.empty()) {
             int u = q.front(); q.pop();
-            for (const auto &vw : g.adj_list[u]) {
-                if (vw.second != 0) continue;
-                if (!visited.insert(vw.first).second) continue;
-                if (g.haplotype.at(vw.first) == target_hap && g.original_vertex.at(vw.first).size() > 0) return vw.first;
-                q.push(vw.first);
+            for (int64_t e = g.adj_off[u]; e < g.adj_off[u + 1]; ++e) {
+                const int v = g.adj_dst[e];
+                if (g.adj_w[e] != 0) continue;
+                if (!visited.insert(v).second) continue;
+                if (g.haplotype.at(v) == target_hap && g.orig_len.at(v) > 0) return v;
+                q.push(v);
             }
         }
         return -1;
@@ -843,20 +948,22 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
         const auto &wedges = which == 0 ? wp1 : wp2;
         const char *tag = which == 0 ? "P1" : "P2";
         std::string &hs = hap_seq[which];
-        int start_exp = g.vertices_in_level.at(0).at(0);
+        const int first_vertex = g.level_off.at(0);                   // vertices_in_level[0][0]
+        int start_exp = first_vertex;
         for (int i = 0; i < (int)wedges.size(); i++) {
             const auto &edge = wedges.at(i);
-            if (g.original_vertex[edge.first].size() != 1) {
-                std::cout << tag << ": Vertex " << edge.first << " in map back has " << g.original_vertex[edge.first].size()
+            if (g.orig_len[edge.first] != 1) {
+                std::cout << tag << ": Vertex " << edge.first << " in map back has " << g.orig_len[edge.first]
                           << " original vertices" << std::endl;
                 exit(1);
             }
             int end_exp = edge.first;
             int h = g.haplotype.at(end_exp);
-            if (start_exp == g.vertices_in_level.at(0).at(0))
-                for (auto &v : g.vertices_in_level.at(1)) if (g.haplotype.at(v) == h) start_exp = v;
-            int start_org = g.original_vertex.at(start_exp).at(0);
-            int end_org = g.original_vertex.at(end_exp).at(0);
+            if (start_exp == first_vertex)
+                for (int v = g.level_off.at(1); v < g.level_off.at(2); ++v) if (g.haplotype.at(v) == h) start_exp = v;
+            if (g.orig_len.at(start_exp) < 1 || g.orig_len.at(end_exp) < 1) throw std::out_of_range("original_vertex.at(0)");
+            int start_org = g.orig_pool[g.orig_off[start_exp]];
+            int end_org = g.orig_pool[g.orig_off[end_exp]];
             bool activated = false;
             for (int t = 0; t < (int)paths[h].size(); t++) {
                 if ((int)paths[h][t] == start_org) activated = true;
@@ -925,6 +1032,9 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
 
 int Pipeline::run(std::string &err) {                                  // main.cpp:117-165
     sum = Summary();
+#ifdef _OPENMP
+    omp_set_num_threads(std::max(1, opt.threads));
+#endif
     double t0 = now_s();
     if (load_graph(err)) return -1;
     if (opt.ploidy != 1 && opt.ploidy != 2) {

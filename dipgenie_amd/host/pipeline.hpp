@@ -29,6 +29,7 @@ struct Backend {     // same signatures as the C ABI, plus an opaque ctx
     int (*sketch_haplotype)(void *, const char *, int64_t, int, int, uint64_t **, int64_t **, int64_t *) = nullptr;
     int (*dp_solve_diploid)(void *, const dg_dp_graph *, dg_dp_result *) = nullptr;
     void (*free_buf)(void *) = nullptr;
+    void (*hint_dp_soon)(void *) = nullptr;   // optional: the DP will be called later in this run (lets the device side prepare)
     const char *(*last_error)() = nullptr;
 };
 
@@ -45,12 +46,26 @@ struct Options {
     bool dump_only = false;   // (ours, tests) stop after the dump
 };
 
-struct ExpandedGraph {        // ExpandedGraph.hpp:16-26
-    std::vector<int> level, haplotype;
-    std::vector<std::vector<int>> color, original_vertex, vertices_in_level;
-    std::vector<std::vector<std::pair<int, int>>> adj_list;
+// ExpandedGraph.hpp:16-26, flattened: CSR adjacency (per-vertex order = the reference's push order),
+// CSR colours, and original-vertex lists as (offset, length) into one pool (dummies share their
+// parent's list instead of copying it, ExpandedGraph.hpp:330).
+struct ExpandedGraph {
+    int32_t n = 0;
+    std::vector<int64_t> adj_off;               // [n+1]
+    std::vector<int32_t> adj_dst;
+    std::vector<uint8_t> adj_w;
+    std::vector<int32_t> haplotype, level;
+    std::vector<uint32_t> orig_off, orig_len;
+    std::vector<int32_t> orig_pool;
+    std::vector<int64_t> col_off;               // [n+1]
+    std::vector<int32_t> col_pool;
+    std::vector<int32_t> level_off;             // [L+1] after levelize (vertex ids are level-sorted)
+    int64_t deg(int v) const { return adj_off[v + 1] - adj_off[v]; }
+    int64_t ncol(int v) const { return col_off[v + 1] - col_off[v]; }
     void topologically_reorder(int sink);
     int strict_bfs_levelize_and_reorder();
+  private:
+    void permute(const std::vector<int32_t> &order);   // new vertex i = old vertex order[i]
 };
 
 struct AnchorRec {            // approximator.h:11-18

@@ -74,6 +74,9 @@ typedef struct dg_dp_timing {         /* HIP-event times of the last dg_dp_run, 
     uint64_t state_bytes, bp_bytes, delta_bytes;   /* device allocations */
 } dg_dp_timing;
 
+/* optional: start reserving the back-pointer lattice in a background thread (bytes <= 0: 60 % of the free
+ * HBM). A 100+ GB hipMalloc takes seconds; the CLI overlaps it with the host stages. */
+int dg_dp_prealloc(dg_ctx *, int64_t bytes);
 int dg_dp_load_graph(dg_ctx *, const dg_dp_graph *);   /* validate + upload + build in-CSR; resident until next load */
 int dg_dp_run(dg_ctx *, dg_dp_result *);               /* all kernels on the resident graph; synchronises */
 int dg_dp_get_timing(dg_ctx *, dg_dp_timing *);

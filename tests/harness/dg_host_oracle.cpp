@@ -15,14 +15,51 @@
 #include "../../dipgenie_amd/host/pipeline.hpp"
 #include "../../oracle/oracle.h"
 
+// Optional on-disk cache of the oracle's sketches (-C dir): the literal string-based restatement needs ~95 s for
+// 24 x 5 Mbp; host-stage work on big graphs re-uses its outputs. Keyed by a checksum of the input bytes.
+static std::string g_cache;
+static uint64_t fnv(const char *p, int64_t n, uint64_t h = 1469598103934665603ULL) {
+    for (int64_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ULL; }
+    return h;
+}
+template <class A, class B> static bool cache_load(const std::string &f, A **a, B **b, int64_t *n) {
+    FILE *fp = fopen(f.c_str(), "rb");
+    if (!fp) return false;
+    bool ok = fread(n, 8, 1, fp) == 1;
+    if (ok) {
+        *a = (A *)malloc(sizeof(A) * (*n + 1)); *b = (B *)malloc(sizeof(B) * (*n + 1));
+        ok = fread(*a, sizeof(A), *n, fp) == (size_t)*n && fread(*b, sizeof(B), *n, fp) == (size_t)*n;
+    }
+    fclose(fp);
+    return ok;
+}
+template <class A, class B> static void cache_save(const std::string &f, const A *a, const B *b, int64_t n) {
+    FILE *fp = fopen(f.c_str(), "wb");
+    if (!fp) return;
+    fwrite(&n, 8, 1, fp); fwrite(a, sizeof(A), n, fp); fwrite(b, sizeof(B), n, fp);
+    fclose(fp);
+}
 static int o_sketch_reads(void *, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **c, int64_t *nd) {
-    return orc_sketch_reads(b, off, n, k, w, h, c, nd);
+    std::string f;
+    if (!g_cache.empty()) {
+        f = g_cache + "/reads_" + std::to_string(fnv(b, off[n], fnv((const char *)off, 8 * (n + 1)))) + "_" + std::to_string(k) + "_" + std::to_string(w);
+        if (cache_load(f, h, c, nd)) return 0;
+    }
+    int rc = orc_sketch_reads(b, off, n, k, w, h, c, nd);
+    if (rc == 0 && !f.empty()) cache_save(f, *h, *c, *nd);
+    return rc;
 }
 static int o_sketch_hap(void *, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) {
+    std::string f;
+    if (!g_cache.empty()) {
+        f = g_cache + "/hap_" + std::to_string(fnv(s, len)) + "_" + std::to_string(k) + "_" + std::to_string(w);
+        if (cache_load(f, h, p, n)) return 0;
+    }
     int64_t cnt = orc_minimizers(s, len, k, w, nullptr, nullptr, 0);
     *h = (uint64_t *)malloc(sizeof(uint64_t) * (cnt + 1));
     *p = (int64_t *)malloc(sizeof(int64_t) * (cnt + 1));
     *n = orc_minimizers(s, len, k, w, *h, *p, cnt);
+    if (!f.empty()) cache_save(f, *h, *p, *n);
     return 0;
 }
 static int o_dp(void *, const dg_dp_graph *g, dg_dp_result *r) {
@@ -50,7 +87,7 @@ int main(int argc, char **argv) {
     dg::Pipeline p;
     std::string json;
     int c;
-    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:qX")) >= 0) {
+    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:qXC:")) >= 0) {
         switch (c) {
         case 't': p.opt.threads = atoi(optarg); break;
         case 'p': p.opt.ploidy = atoi(optarg); break;
@@ -66,6 +103,7 @@ int main(int argc, char **argv) {
         case 'J': json = optarg; break;
         case 'q': p.opt.quiet = true; break;
         case 'X': p.opt.dump_only = true; break;
+        case 'C': g_cache = optarg; break;
         }
     }
     p.be.sketch_reads = o_sketch_reads;
