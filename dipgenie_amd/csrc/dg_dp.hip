@@ -1112,7 +1112,7 @@ extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
     if (S.pre_thread.joinable() || S.pre_ptr) return DG_OK;           // already reserving
     size_t free_b = 0, total_b = 0;
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t want = bytes > 0 ? (size_t)bytes : (size_t)(0.6 * (double)free_b);
+    size_t want = bytes > 0 ? std::min((size_t)bytes, (size_t)(0.6 * (double)free_b)) : (size_t)(0.6 * (double)free_b);
     if (want + ((size_t)8 << 30) > free_b) want = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
     if (want <= S.d_bp.bytes || want == 0) return DG_OK;
     const int dev = c->device;

@@ -20,7 +20,10 @@ static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint6
     return dg_sketch_haplotype((dg_ctx *)c, s, len, k, w, h, p, n);
 }
 static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
-static void b_hint(void *c) { dg_dp_prealloc((dg_ctx *)c, 0); }   // overlap the lattice reservation with the host stages
+static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reservation (4 B/cell) with the host stages
+    const double bytes = 4.0 * (double)est_cells * 1.5;
+    if (bytes >= 4e9) dg_dp_prealloc((dg_ctx *)c, bytes > 8e18 ? 0 : (int64_t)bytes);   // small lattices allocate instantly anyway
+}
 
 static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
     fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");

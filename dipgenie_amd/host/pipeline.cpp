@@ -207,7 +207,12 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
 
     // ---- compute_anchors (solver.cpp:415-446, 560-575): hap minimizers whose hash is in Sp_R ----
     t0 = now_s();
-    if (opt.ploidy == 2 && be.hint_dp_soon) be.hint_dp_soon(be.ctx);   // device work of the sketches is done: reserve the DP lattice now
+    if (opt.ploidy == 2 && be.hint_dp_soon) {       // device work of the sketches is done: let the device side reserve the DP lattice
+        size_t max_path = 0;
+        for (auto &pw : paths) max_path = std::max(max_path, pw.size());
+        const double kk = 4.0 * (double)num_walks;  // level width ~ walks x (chain + recombination + dummy vertices)
+        be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, (double)max_path * kk * kk * (opt.R + 1)));
+    }
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
     std::vector<std::vector<int32_t>> ids(num_walks);

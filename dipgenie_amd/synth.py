@@ -108,6 +108,62 @@ def random_bubble_graph(seed, n_bubbles=12, n_haps=4, seg_len=(20, 60), alleles=
     return segs, links, walks, reads
 
 
+def linear_panel(seed, backbone_bp=200_000, n_haps=100, bubble_every=64, switch_bp=50_000, coverage=4.0, read_len=150,
+                 sub_rate=0.002, sample=(0, 1)):
+    """chr22-style stand-in (BASELINE configs[4], scaled by backbone_bp): uniform random backbone, one biallelic
+    bubble every ~bubble_every bp (80 % SNP, 20 % 1-50 bp indel), n_haps walks from a copying model that switches
+    template every ~switch_bp. Returns (seg_seqs, links, walks, reads)."""
+    rng = np.random.default_rng(seed)
+    segs, links, layers = [], [], []
+    pos = 0
+    while pos < backbone_bp:
+        ln = int(rng.geometric(1.0 / bubble_every)) + 1
+        layers.append([len(segs)])
+        segs.append(_rand_seq(rng, ln))
+        pos += ln
+        if pos >= backbone_bp:
+            break
+        ref = _rand_seq(rng, 1)
+        if rng.random() < 0.8:
+            alt = bytes([b"ACGT"[(b"ACGT".index(ref) + 1 + int(rng.integers(0, 3))) % 4]])
+        else:
+            alt = ref + _rand_seq(rng, int(rng.integers(1, 51)))
+        layers.append([len(segs), len(segs) + 1])
+        segs += [ref, alt]
+        pos += 1
+    if len(layers[-1]) != 1:
+        layers.append([len(segs)])
+        segs.append(_rand_seq(rng, 40))
+    for x, y in zip(layers[:-1], layers[1:]):
+        for a in x:
+            for b in y:
+                links.append((a, b))
+    # founders = 8 random allele vectors; haplotypes copy a founder and switch every ~switch_bp
+    n_bub = sum(1 for l in layers if len(l) == 2)
+    founders = rng.integers(0, 2, (8, n_bub))
+    walks = []
+    for h in range(n_haps):
+        f = int(rng.integers(0, 8))
+        acc, nxt, b = 0, int(rng.exponential(switch_bp)) + 100, 0
+        w = []
+        for l in layers:
+            if len(l) == 1:
+                v = l[0]
+            else:
+                v = l[int(founders[f, b])]
+                b += 1
+            w.append(v)
+            acc += len(segs[v])
+            if acc >= nxt:
+                f = int(rng.integers(0, 8))
+                nxt = acc + int(rng.exponential(switch_bp)) + 100
+        walks.append(("hap%03d" % h, h, w))
+    hap_strs = [b"".join(segs[v] for v in walks[h][2]) for h in sample]
+    n_reads = int(coverage * sum(len(x) for x in hap_strs) / 2 / read_len)
+    reads = simulate_reads(rng, hap_strs, n_reads, read_len, sub_rate)
+    return segs, links, walks, reads
+
+
 # ------------------------------------------------------------------------------------------------
 def parse_gfa(path):
     """Minimal S/L/W reader (forward-strand graphs only). Returns (names, seqs, links, walks)."""

@@ -126,6 +126,14 @@ def e2e():
         ("bub_c_p1", dict(seed=3, n_bubbles=40, n_haps=8, coverage=8.0, sub_rate=0.01), ["-p1", "-R8", "-k13", "-w7"]),
     ]
     ed = os.path.join(HERE, "e2e")
+    # chr22-style stand-in (BASELINE configs[4], scaled down): 100 haplotypes, R = 32
+    gfa, reads = os.path.join(ed, "c5s.gfa"), os.path.join(ed, "c5s.fa")
+    if not os.path.exists(gfa):
+        segs, links, walks, rd = synth.linear_panel(22, backbone_bp=8000, n_haps=100)
+        synth.write_gfa(gfa, segs, links, walks)
+        synth.write_fasta(reads, rd)
+    cases["c5s"] = dict(gfa="tests/golden/e2e/c5s.gfa", reads="tests/golden/e2e/c5s.fa", **run_ref(gfa, reads, ["-p2", "-R32"], threads=8))
+    print("c5s", cases["c5s"].get("dp_value"), cases["c5s"].get("r1"), cases["c5s"].get("r2"), cases["c5s"]["fasta_md5"], flush=True)
     for name, kw, args in specs:
         base = name.replace("_p1", "")
         gfa, reads = os.path.join(ed, base + ".gfa"), os.path.join(ed, base + ".fa")
@@ -139,6 +147,10 @@ def e2e():
     cases["mhc4_p2"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p2", "-R18"],
                             fasta_md5="46394489af8bc9026605ddf237aca4c7", dp_value=60729, r1=17, r2=1, len1=5005629, len2=4920284,
                             obj=5282, spectrum=138834, slow=True)
+    cases["mhc24_p2"] = dict(gfa="<synth.ensure_mhc24>", reads="<synth.ensure_mhc24>", args=["-p2", "-R18"],
+                             fasta_md5="cd13930ac90651b7e441506c1ecd4514", dp_value=331848, r1=10, r2=8, len1=5042783, len2=5032337, obj=64156,
+                             slow=True, note="reference (oracle/_ref/DipGenie_ref -t8) on dipgenie_amd.synth.mosaic_panel(seed=24, "
+                             "read_seed=4): 892.6 s wall, DP 731.8 s, RSS 9.8 GB")
     cases["mhc4_p1"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p1"],
                             fasta_md5="0c4df87ded10634a36db0a2c90521ff0", best_r_haploid=0, spectrum=138834, slow=True)
     return cases

@@ -131,6 +131,55 @@ def test_dp_random_levelized(gpu_ctx, seed):
     _dp_both(gpu_ctx, g)
 
 
+@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive"])
+def test_dp_alternative_kernels(gpu_ctx, mode):
+    """the generic fallback sweep, the one-XCD team kernel and the fixed-RC launch must all give the oracle's answer"""
+    opts = {"generic": {"fast": 0}, "team": {"team": 1, "team_min_levels": 4, "team_max_tasks": 4096}, "no_adaptive": {"adaptive_rc": 0}}[mode]
+    try:
+        for k, v in opts.items():
+            gpu_ctx.dp_set_option(k, v)
+        for seed, kw in [(1, dict(max_width=12, n_levels=300, R=5)), (2, dict(max_width=40, n_levels=60, R=18, p_w1=0.5)),
+                         (3, dict(max_width=6, n_levels=2000, R=3, p_colour=0.2)), (4, dict(R=33, max_width=20, n_levels=50))]:
+            g = graphgen.random_levelized(7000 + seed, **kw)
+            out = gpu_ctx.dp_solve(g)
+            ref = orc.dp_solve(g)
+            assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"]), (mode, seed)
+    finally:
+        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 1}.items():
+            gpu_ctx.dp_set_option(k, v)
+
+
+def test_dp_giant_indegree_uses_generic_path(gpu_ctx):
+    """a vertex with in-degree > 64 (more than 64 haplotypes recombining into one vertex) leaves the fast path"""
+    k = 90
+    level_off = np.array([0, 1, 1 + k, 2 + k, 3 + k], np.int32)
+    out, w = [], []
+    out_off = [0]
+    for j in range(k):                                        # source -> k vertices
+        out.append(1 + j); w.append(0)
+    out_off.append(len(out))
+    for j in range(k):                                        # all k -> one vertex (in-degree 90), alternating weights per source
+        out.append(1 + k); w.append(j & 1)
+        out_off.append(len(out))
+    out.append(2 + k); w.append(0); out_off.append(len(out))  # -> sink
+    out_off.append(len(out))
+    nV = 3 + k
+    hom = [[] for _ in range(nV)]
+    het = [[] for _ in range(nV)]
+    for j in range(k):
+        het[1 + j] = [j % 7]
+        hom[1 + j] = [10 + j % 5]
+    hom[1 + k] = [10, 12]
+    het[1 + k] = [3]
+    def csr(ls):
+        off = np.zeros(nV + 1, np.int64); off[1:] = np.cumsum([len(x) for x in ls])
+        return off, np.array([c for x in ls for c in x], np.int32)
+    ho, hc = csr(hom); to, tc = csr(het)
+    g = capi.DpGraphArrays(2, level_off=level_off, out_off=np.array(out_off, np.int64), out_dst=np.array(out, np.int32),
+                           out_w=np.array(w, np.uint8), hom_off=ho, hom_col=hc, het_off=to, het_col=tc)
+    _dp_both(gpu_ctx, g)
+
+
 def test_dp_unreachable_sink(gpu_ctx):
     # every path to the sink needs 2 recombinations but R = 1: value stays NEG_INF, edge lists empty
     lo = np.array([0, 1, 2, 3], np.int32)
@@ -172,7 +221,7 @@ def _run_cli(cli, case, tmp_path, extra=()):
     return open(out, "rb").read(), json.load(open(js))
 
 
-@pytest.mark.parametrize("name", [n for n, c in CASES.items() if not c.get("slow")])
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<")])
 def test_cli_e2e_small(built_hip, gpu_ctx, name, tmp_path):
     fa, summ = _run_cli(built_hip, CASES[name], tmp_path)
     assert hashlib.md5(fa).hexdigest() == CASES[name]["fasta_md5"]
@@ -190,6 +239,16 @@ def test_cli_e2e_mhc4_diploid(built_hip, gpu_ctx, tmp_path):
     assert (summ["dp_value"], summ["r1"], summ["r2"], summ["spectrum"]) == (60729, 17, 1, 138834)
     assert summ["cells"] == 421330909 and summ["relaxations"] == 659218148
     _dp_both(gpu_ctx, capi.DpGraphArrays.load(str(tmp_path / "mhc4.dpg")))
+
+
+def test_cli_e2e_mhc24_synthetic(built_hip, gpu_ctx, tmp_path):
+    """BASELINE config 3 (the bench workload): the seeded synthetic MHC-24; the reference needed 892.6 s for it"""
+    c = CASES["mhc24_p2"]
+    gfa, reads, _ = synth.ensure_mhc24(str(tmp_path / "mhc24"))
+    case = dict(c, gfa=os.path.relpath(gfa, ROOT), reads=os.path.relpath(reads, ROOT))
+    fa, summ = _run_cli(built_hip, case, tmp_path)
+    assert hashlib.md5(fa).hexdigest() == c["fasta_md5"] == "cd13930ac90651b7e441506c1ecd4514"
+    assert (summ["dp_value"], summ["r1"], summ["r2"]) == (331848, 10, 8)
 
 
 def test_cli_e2e_mhc4_haploid(built_hip, gpu_ctx, tmp_path):

@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CASES = json.load(open(os.path.join(HERE, "golden", "e2e.json")))
-FAST = [n for n, c in CASES.items() if not c.get("slow")]
+FAST = [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<")]
 
 
 def run_case(binary, case, tmp_path, extra=()):
