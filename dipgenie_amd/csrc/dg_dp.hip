@@ -52,6 +52,11 @@ struct DpState {
     int last_team_size = 0;
     bool all_fast = false;
     int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 1, chip_waves = 8192;
+    // lattice segments: destination levels [seg_begin[s], seg_begin[s+1]); one segment = whole lattice resident.
+    // More than one = checkpoint + recompute (value-only pass, then each segment re-swept with back-pointers, last first).
+    std::vector<int> seg_begin;
+    std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
+    int64_t segment_cells = 0;                          // option: force segments of at most this many cells (tests)
     struct Segment { int begin, end; bool team; };
     std::vector<Segment> schedule;
     size_t state_alloc_bytes = 0;
@@ -59,7 +64,7 @@ struct DpState {
     uint64_t cells = 0, relaxations = 0, edge_pairs = 0, colour_entries = 0;
     int64_t total_cells = 0, max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path;
+    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -272,7 +277,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r2 < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                     nxt[idx] = bval[q];
-                    A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                    if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
                     if (DIGEST && bval[q] != NEG_INF) {
                         const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                         dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -287,7 +292,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r0 + q < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                     nxt[idx] = NEG_INF;
-                    A.bp[d.bp_off + idx] = BP_NONE;
+                    if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
                 }
             }
         }
@@ -442,7 +447,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r2 < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                 nxt[idx] = bval[q];
-                A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
                 if (DIGEST && bval[q] != NEG_INF) {
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -456,7 +461,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                 nxt[idx] = NEG_INF;
-                A.bp[d.bp_off + idx] = BP_NONE;
+                if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
             }
         }
     }
@@ -599,46 +604,54 @@ __global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, ever
 
 // ---------------------------------------------------------------------------------------------
 // traceback   (approximator.cpp:757-785)
-// Phase 1 (wave 0): walk the back-pointer lattice from the sink cell (r = R, i = j = 0).  The chain is one
+// Chain kernel (one wave): walk the back-pointer lattice downwards from a known cell.  The chain is one
 // dependent HBM load per level, so everything else is kept off it: the level descriptors of the next 64
 // levels are fetched one per lane and broadcast with readlane, and the hop words are parked in path[].
-// Phase 2 (all 1024 threads, levels in parallel): re-derive s_het from the colour lists of the winning
+// In segmented mode it is called once per segment, last segment first, carrying the cell in `st`.
+// Finish kernel (1024 threads, levels in parallel): re-derive s_het from the colour lists of the winning
 // edge pairs (:662) and emit the weighted edges (:673-692; both final edges unconditionally) as
 // (level, from, to, which) records; the host orders them by level.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void dp_traceback_kernel(const LevelDesc *__restrict__ descs, int L, int RP, int R,
-                                                            const uint32_t *__restrict__ bp, const int32_t *__restrict__ final_val,
-                                                            ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
-                                                            uint32_t *__restrict__ path /* L */, TraceOut *out) {
-    __shared__ int s_value, s_shet, s_ne;
+struct ChainState { int32_t i, j, r, value; };
+
+__global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
+                                                            const uint32_t *__restrict__ bp /* biased by the segment's first cell */,
+                                                            const int32_t *__restrict__ final_val /* non-null on the first call */,
+                                                            uint32_t *__restrict__ path, ChainState *st) {
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) {
-        const int value = final_val[(int64_t)R * descs[L - 1].k2];   // sink level, layout [i][r][j]: cell (i=0, r=R, j=0)
-        if (threadIdx.x == 0) { s_value = value; s_shet = 0; s_ne = 0; }
-        if (value != NEG_INF) {
-            int i = 0, j = 0, r = R;                                  // wave-uniform
-            for (int base = L - 1; base >= 1; base -= 64) {
-                const int my_l = base - lane;
-                long long bo = 0;
-                int kk = 1;
-                if (my_l >= 1) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; }
-                const int n = min(64, base);
-                for (int t = 0; t < n; ++t) {
-                    const int l = base - t;
-                    const long long bo_l = ((long long)__builtin_amdgcn_readlane((int)(bo >> 32), t) << 32) |
-                                           (unsigned int)__builtin_amdgcn_readlane((int)bo, t);
-                    const int k2 = __builtin_amdgcn_readlane(kk, t);
-                    const uint32_t b = bp[bo_l + ((long long)i * RP + r) * k2 + j];
-                    if (lane == 0) path[l] = b;
-                    i = (int)(b & 0x7FFFu); j = (int)((b >> 15) & 0x7FFFu);
-                    r -= (int)((b >> 30) & 1u) + (int)(b >> 31);
-                }
+    int i, j, r, value;
+    if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; i = 0; j = 0; r = R; }   // sink level, layout [i][r][j]: cell (0, R, 0)
+    else { i = st->i; j = st->j; r = st->r; value = st->value; }
+    if (value != NEG_INF) {
+        for (int base = l_hi; base >= l_lo; base -= 64) {
+            const int my_l = base - lane;
+            long long bo = 0;
+            int kk = 1;
+            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; }
+            const int n = min(64, base - l_lo + 1);
+            for (int t = 0; t < n; ++t) {
+                const int l = base - t;
+                const long long bo_l = ((long long)__builtin_amdgcn_readlane((int)(bo >> 32), t) << 32) |
+                                       (unsigned int)__builtin_amdgcn_readlane((int)bo, t);
+                const int k2 = __builtin_amdgcn_readlane(kk, t);
+                const uint32_t b = bp[bo_l + ((long long)i * RP + r) * k2 + j];
+                if (lane == 0) path[l] = b;
+                i = (int)(b & 0x7FFFu); j = (int)((b >> 15) & 0x7FFFu);
+                r -= (int)((b >> 30) & 1u) + (int)(b >> 31);
             }
         }
     }
-    __threadfence_block();
+    if (lane == 0) { st->i = i; st->j = j; st->r = r; st->value = value; }
+}
+
+__global__ __launch_bounds__(1024) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
+                                                               ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
+                                                               const ChainState *st, TraceOut *out) {
+    __shared__ int s_shet, s_ne;
+    if (threadIdx.x == 0) { s_shet = 0; s_ne = 0; }
     __syncthreads();
-    if (s_value != NEG_INF) {
+    const int value = st->value;
+    if (value != NEG_INF) {
         int shet = 0;
         for (int l = 1 + (int)threadIdx.x; l < L; l += (int)blockDim.x) {
             const uint32_t b = path[l];
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(1024) void dp_traceback_kernel(const LevelDesc *__r
     __syncthreads();
     if (threadIdx.x == 0) {
         TraceOut o;
-        o.value = s_value; o.s_het = s_shet; o.n_e = s_ne; o.overflow = s_ne > cap_e ? 1 : 0;
+        o.value = value; o.s_het = s_shet; o.n_e = s_ne; o.overflow = s_ne > cap_e ? 1 : 0;
         *out = o;
     }
 }
@@ -862,18 +875,50 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         S.pre_ptr = nullptr; S.pre_bytes = 0;
     }
     lap("join prealloc");
-    // memory budget
-    const size_t bp_bytes = (size_t)S.total_cells * 4, st_bytes = (size_t)S.max_level_cells * 4 * 2,
-                 dl_bytes = (size_t)S.delta_entries * 2;
+    // memory budget and lattice segmentation
+    const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_entries * 2;
     size_t free_b = 0, total_b = 0;
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t have = free_b + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes;
-    if (bp_bytes + st_bytes + dl_bytes + ((size_t)1 << 30) > have) {
-        set_error("back-pointer lattice needs %.1f GB (+%.1f GB state/delta) but only %.1f GB of HBM is free; "
-                  "segmented (checkpoint + recompute) mode is not implemented yet",
-                  bp_bytes / 1e9, (st_bytes + dl_bytes) / 1e9, have / 1e9);
+    const size_t have = free_b + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes + S.d_ckpt.bytes;
+    const size_t fixed = st_bytes + dl_bytes + 64 * (size_t)nV + ((size_t)2 << 30);     // state, delta, tables, slack
+    if (fixed > have) {
+        set_error("graph needs %.1f GB of HBM for state/delta/tables but only %.1f GB is free", fixed / 1e9, have / 1e9);
         return DG_ERR_OOM;
     }
+    int64_t seg_cap_cells = (int64_t)((have - fixed) / 4);                            // back-pointer cells that fit
+    bool segmented = S.total_cells > seg_cap_cells || S.segment_cells > 0;
+    if (segmented) {
+        // keep half of the room for the checkpoints; a segment must hold at least its largest level
+        seg_cap_cells = S.segment_cells > 0 ? S.segment_cells : seg_cap_cells / 2;
+        seg_cap_cells = std::max<int64_t>(seg_cap_cells, S.max_level_cells);
+    }
+    S.seg_begin.assign(1, 1);
+    S.ckpt_off.assign(1, 0);
+    int64_t max_seg_cells = 0, ckpt_cells = 0;
+    {
+        int64_t acc = 0;
+        for (int l = 1; l < L; ++l) {
+            const int64_t ncell = (int64_t)S.descs[l].k2 * S.descs[l].k2 * S.RP;
+            if (segmented && acc > 0 && acc + ncell > seg_cap_cells) {
+                S.seg_begin.push_back(l);
+                S.ckpt_off.push_back(ckpt_cells);
+                ckpt_cells += (int64_t)S.descs[l].k * S.descs[l].k * S.RP;            // state of level l-1
+                max_seg_cells = std::max(max_seg_cells, acc);
+                acc = 0;
+            }
+            acc += ncell;
+        }
+        max_seg_cells = std::max(max_seg_cells, acc);
+        S.seg_begin.push_back(L);
+    }
+    const size_t bp_bytes = (size_t)max_seg_cells * 4, ck_bytes = (size_t)ckpt_cells * 4;
+    if (bp_bytes + ck_bytes + fixed > have) {
+        set_error("segmented lattice needs %.1f GB (+%.1f GB checkpoints) but only %.1f GB of HBM is free", bp_bytes / 1e9, ck_bytes / 1e9, have / 1e9);
+        return DG_ERR_OOM;
+    }
+    if (dbg && S.seg_begin.size() > 2)
+        fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_cells * 4 / 1e9,
+                S.seg_begin.size() - 1, bp_bytes / 1e9, ck_bytes / 1e9);
     hipStream_t s = c->stream;
     if (int rc = upload(S.d_descs, S.descs.data(), sizeof(LevelDesc) * L, s)) return rc;
     if (int rc = upload(S.d_in_off, in_off.data(), 4 * in_off.size(), s)) return rc;
@@ -893,6 +938,8 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_bp.ensure(bp_bytes)) return rc;
+    if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
+    if (int rc = S.d_chain.ensure(sizeof(ChainState))) return rc;
     S.pad_front = 2 * (int64_t)max_k;
     const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)max_k);
     if (int rc = S.d_val[0].ensure(st_bytes / 2 + pad_bytes)) return rc;
@@ -928,10 +975,108 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     hipStream_t s = c->stream;
     const LevelDesc *descs = S.d_descs.as<LevelDesc>();
     ColourCsr col{S.d_hom_off.as<int64_t>(), S.d_het_off.as<int64_t>(), S.d_hom_col.as<int32_t>(), S.d_het_col.as<int32_t>()};
-    const int n_dtrans = (int)(S.d_dtrans.bytes && S.n_delta_blocks ? 0 : 0);
-    (void)n_dtrans;
-    bool team_failed = false;
+    const int rc_sel = S.RP <= 8 ? 8 : (S.RP <= 19 ? 19 : 33);
+    const int nchunk = (S.RP + rc_sel - 1) / rc_sel;
+    const bool small_state = S.state_alloc_bytes < ((size_t)1 << 31);   // 32-bit buffer offsets
+    SweepArgs A;
+    A.descs = descs; A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
+    A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
+    A.delta = S.d_delta.as<uint16_t>();
+    A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
+    A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
+    FastArgs F;
+    F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.dead_cols = A.dead_cols;
+    F.delta = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
+    F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
+    F.pad_bytes = (int)(4 * S.pad_front);
+    F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
+    int64_t n_launch = 0;
+    uint32_t team_err = 0;
+    bool team_used = false, team_failed = false;
+    int n_team_launch = 0;
+
+    // Sweeps destination levels [lb, le).  bp_biased = lattice pointer minus the offset of level lb's first cell
+    // (so the kernels keep using the global LevelDesc::bp_off), or nullptr for a value-only pass.
+    auto sweep_range = [&](int lb, int le, uint32_t *bp_biased) -> int {
+        A.bp = bp_biased; F.bp = bp_biased;
+        // runs of narrow levels may go to the one-XCD team kernel (one launch per run, optional); every other level
+        // gets one whole-chip launch
+        const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed;
+        S.schedule.clear();
+        for (int l = lb; l < le;) {
+            auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok && (int64_t)d.k2 * d.ngroups <= S.team_max_tasks; };
+            int e = l;
+            if (narrow(l)) { while (e < le && narrow(e)) ++e; }
+            const bool is_team = e - l >= S.team_min_levels;
+            if (!is_team) e = std::max(e, l + 1);
+            if (!is_team && !S.schedule.empty() && !S.schedule.back().team) S.schedule.back().end = e;
+            else S.schedule.push_back({l, e, is_team});
+            l = e;
+        }
+        for (const auto &seg : S.schedule) {
+            if (seg.team) {
+                TeamCtl *ctl = S.d_ctrl.as<TeamCtl>() + (n_team_launch % TEAM_CTL_SLOTS);
+                DG_HIP(hipMemsetAsync(ctl, 0, sizeof(TeamCtl), s));
+                const dim3 grid((unsigned)S.team_grid);
+#define DG_TEAM(RCV) hipLaunchKernelGGL((dp_team_kernel<RCV, false>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl)
+                if (rc_sel == 19 && getenv("DG_TEAM_PROF")) hipLaunchKernelGGL((dp_team_kernel<19, true>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl);
+                else if (rc_sel == 8) DG_TEAM(8); else if (rc_sel == 19) DG_TEAM(19); else DG_TEAM(33);
+#undef DG_TEAM
+                team_used = true;
+                ++n_team_launch;
+                ++n_launch;
+                if (n_team_launch % TEAM_CTL_SLOTS == 0) {      // ctl slots are recycled: check the finished ones first
+                    std::vector<TeamCtl> hc(TEAM_CTL_SLOTS);
+                    DG_HIP(hipMemcpyAsync(hc.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
+                    DG_HIP(hipStreamSynchronize(s));
+                    for (auto &h : hc) if (h.error) team_err = h.error;
+                    if (team_err) return DG_OK;
+                }
+                continue;
+            }
+            for (int l = seg.begin; l < seg.end; ++l) {
+                const LevelDesc &d = S.descs[l];
+                if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
+                    // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
+                    // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
+                    const int64_t base = (int64_t)d.k2 * d.ngroups;
+                    int rc = rc_sel;
+                    if (S.adaptive_rc) {
+                        if (base * S.RP <= S.chip_waves) rc = 1;
+                        else if (base * ((S.RP + 1) / 2) <= S.chip_waves) rc = 2;
+                        else if (base * ((S.RP + 3) / 4) <= S.chip_waves) rc = 4;
+                        if (rc > rc_sel) rc = rc_sel;
+                    }
+                    const int nch = (S.RP + rc - 1) / rc;
+                    const dim3 grid((unsigned)((d.ngroups + 3) / 4), (unsigned)(d.k2 * nch));
+#define DG_FAST(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG>), grid, dim3(256), 0, s, F, d, l)
+#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
+                                        case 8: DG_FAST(8, DG); break; case 19: DG_FAST(19, DG); break; default: DG_FAST(33, DG); break; } } while (0)
+                    if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
+#undef DG_FAST_RC
+#undef DG_FAST
+                } else {
+                    const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
+                    const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
+#define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
+                    if (S.want_digest) { if (rc_sel == 8) DG_SWEEP(8, true); else if (rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
+                    else { if (rc_sel == 8) DG_SWEEP(8, false); else if (rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
+#undef DG_SWEEP
+                }
+                ++n_launch;
+            }
+        }
+        return DG_OK;
+    };
+    auto state_ptr = [&](int level) { return S.d_val[level & 1].as<int32_t>() + S.pad_front; };
+    auto level_cells = [&](int level) -> size_t {      // state size of a level (level 0: the source, k = 1)
+        const int64_t k = level == 0 ? 1 : S.descs[level].k2;
+        return (size_t)(k * k * S.RP);
+    };
+    const int n_seg = (int)S.seg_begin.size() - 1;
+
 retry_forward:
+    n_launch = 0; team_used = false; team_err = 0;
     DG_HIP(hipEventRecord(S.ev[0], s));
     int ndt = 0;
     for (int l = 1; l < S.L; ++l) if (S.descs[l].delta_off >= 0) ++ndt;
@@ -941,100 +1086,40 @@ retry_forward:
                            S.d_delta.as<uint16_t>());
     DG_HIP(hipEventRecord(S.ev[1], s));
     if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
-    hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, S.d_val[0].as<int32_t>() + S.pad_front, S.RP);
-    const int rc_sel = S.RP <= 8 ? 8 : (S.RP <= 19 ? 19 : 33);
-    SweepArgs A;
-    A.descs = descs; A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
-    A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
-    A.delta = S.d_delta.as<uint16_t>();
-    A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
-    A.bp = S.d_bp.as<uint32_t>(); A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
-    FastArgs F;
-    F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.dead_cols = A.dead_cols;
-    F.delta = A.delta; F.bp = A.bp; F.digest = A.digest; F.RP = S.RP;
-    F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
-    F.pad_bytes = (int)(4 * S.pad_front);
-    F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
-    const bool small_state = S.state_alloc_bytes < ((size_t)1 << 31);   // 32-bit buffer offsets
-    const int nchunk = (S.RP + rc_sel - 1) / rc_sel;
-    int64_t n_launch = 0;
-    uint32_t team_err = 0;
-    // schedule: runs of narrow levels go to the one-XCD team kernel (one launch per run), wide levels
-    // get one whole-chip launch each.  A level is "narrow" when the team finishes it in <= ~2 task rounds.
-    const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed;
-    S.schedule.clear();
-    {
-        int l = 1;
-        while (l < S.L) {
-            auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok && (int64_t)d.k2 * d.ngroups <= S.team_max_tasks; };
-            int e = l;
-            if (narrow(l)) { while (e < S.L && narrow(e)) ++e; }
-            const bool is_team = e - l >= S.team_min_levels;
-            if (!is_team) e = std::max(e, l + 1);
-            if (!is_team && !S.schedule.empty() && !S.schedule.back().team) S.schedule.back().end = e;
-            else S.schedule.push_back({l, e, is_team});
-            l = e;
+    hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
+    if (n_seg == 1) {
+        // whole lattice resident: one sweep with back-pointers, one chain walk
+        if (int rc = sweep_range(1, S.L, S.d_bp.as<uint32_t>())) return rc;
+        DG_HIP(hipEventRecord(S.ev[2], s));
+        hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, S.L - 1, 1, S.RP, S.R, S.d_bp.as<uint32_t>(),
+                           state_ptr(S.L - 1), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+    } else {
+        // pass 1: values only, keeping the state in front of every segment
+        const bool dig = S.want_digest;
+        for (int sg = 0; sg < n_seg; ++sg) {
+            if (sg > 0)
+                DG_HIP(hipMemcpyAsync(S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], state_ptr(S.seg_begin[sg] - 1),
+                                      4 * level_cells(S.seg_begin[sg] - 1), hipMemcpyDeviceToDevice, s));
+            if (int rc = sweep_range(S.seg_begin[sg], S.seg_begin[sg + 1], nullptr)) return rc;
         }
+        // pass 2: last segment first -- restore its input state, re-sweep with back-pointers, walk it
+        S.want_digest = 0;                                  // digests were accumulated in pass 1
+        for (int sg = n_seg - 1; sg >= 0; --sg) {
+            const int lb = S.seg_begin[sg], le = S.seg_begin[sg + 1];
+            if (sg > 0)
+                DG_HIP(hipMemcpyAsync(state_ptr(lb - 1), S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], 4 * level_cells(lb - 1), hipMemcpyDeviceToDevice, s));
+            else
+                hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
+            uint32_t *bp_biased = S.d_bp.as<uint32_t>() - S.descs[lb].bp_off;
+            if (int rc = sweep_range(lb, le, bp_biased)) { S.want_digest = dig; return rc; }
+            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, bp_biased,
+                               sg == n_seg - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+        }
+        S.want_digest = dig;
+        DG_HIP(hipEventRecord(S.ev[2], s));
     }
-    bool team = false;
-    int n_team_launch = 0;
-    for (const auto &seg : S.schedule) {
-        if (seg.team) {
-            TeamCtl *ctl = S.d_ctrl.as<TeamCtl>() + (n_team_launch % TEAM_CTL_SLOTS);
-            DG_HIP(hipMemsetAsync(ctl, 0, sizeof(TeamCtl), s));
-            const dim3 grid((unsigned)S.team_grid);
-#define DG_TEAM(RCV) hipLaunchKernelGGL((dp_team_kernel<RCV, false>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl)
-            if (rc_sel == 19 && getenv("DG_TEAM_PROF")) hipLaunchKernelGGL((dp_team_kernel<19, true>), grid, dim3(512), 0, s, F, descs, seg.begin, seg.end, ctl);
-            else if (rc_sel == 8) DG_TEAM(8); else if (rc_sel == 19) DG_TEAM(19); else DG_TEAM(33);
-#undef DG_TEAM
-            team = true;
-            ++n_team_launch;
-            ++n_launch;
-            if (n_team_launch % TEAM_CTL_SLOTS == 0) {      // ctl slots are recycled: check the finished ones first
-                std::vector<TeamCtl> hc(TEAM_CTL_SLOTS);
-                DG_HIP(hipMemcpyAsync(hc.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
-                DG_HIP(hipStreamSynchronize(s));
-                for (auto &h : hc) if (h.error) { team_err = h.error; }
-                if (team_err) break;
-            }
-            continue;
-        }
-        for (int l = seg.begin; l < seg.end; ++l) {
-            const LevelDesc &d = S.descs[l];
-            if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
-                // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
-                // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
-                const int64_t base = (int64_t)d.k2 * d.ngroups;
-                int rc = rc_sel;
-                if (S.adaptive_rc) {
-                    if (base * S.RP <= S.chip_waves) rc = 1;
-                    else if (base * ((S.RP + 1) / 2) <= S.chip_waves) rc = 2;
-                    else if (base * ((S.RP + 3) / 4) <= S.chip_waves) rc = 4;
-                    if (rc > rc_sel) rc = rc_sel;
-                }
-                const int nch = (S.RP + rc - 1) / rc;
-                const dim3 grid((unsigned)((d.ngroups + 3) / 4), (unsigned)(d.k2 * nch));
-#define DG_FAST(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG>), grid, dim3(256), 0, s, F, d, l)
-#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
-                                        case 8: DG_FAST(8, DG); break; case 19: DG_FAST(19, DG); break; default: DG_FAST(33, DG); break; } } while (0)
-                if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
-#undef DG_FAST_RC
-#undef DG_FAST
-            } else {
-                const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
-                const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
-#define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
-                if (S.want_digest) { if (rc_sel == 8) DG_SWEEP(8, true); else if (rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
-                else { if (rc_sel == 8) DG_SWEEP(8, false); else if (rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
-#undef DG_SWEEP
-            }
-            ++n_launch;
-        }
-    }
-    DG_HIP(hipEventRecord(S.ev[2], s));
-    hipLaunchKernelGGL(dp_traceback_kernel, dim3(1), dim3(1024), 0, s, descs, S.L, S.RP, S.R, S.d_bp.as<uint32_t>(),
-                       S.d_val[(S.L - 1) & 1].as<int32_t>() + S.pad_front, col, S.cap, S.d_edges.as<int32_t>(), S.d_path.as<uint32_t>(),
-                       S.d_trace.as<TraceOut>());
+    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3(1), dim3(1024), 0, s, descs, S.L, S.d_path.as<uint32_t>(), col, S.cap,
+                       S.d_edges.as<int32_t>(), S.d_chain.as<ChainState>(), S.d_trace.as<TraceOut>());
     DG_HIP(hipEventRecord(S.ev[3], s));
     DG_HIP(hipGetLastError());
     TraceOut to;
@@ -1047,27 +1132,23 @@ retry_forward:
     }
     std::vector<TeamCtl> ctl_host(TEAM_CTL_SLOTS);
     memset(ctl_host.data(), 0, sizeof(TeamCtl) * TEAM_CTL_SLOTS);
-    if (team) DG_HIP(hipMemcpyAsync(ctl_host.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
+    if (team_used) DG_HIP(hipMemcpyAsync(ctl_host.data(), S.d_ctrl.p, sizeof(TeamCtl) * TEAM_CTL_SLOTS, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
     for (auto &h : ctl_host) if (h.error) team_err = h.error;
-    if (team && team_err) {             // a team could not form or a spin timed out: redo with per-level launches
+    if (team_used && team_err) {        // a team could not form or a spin timed out: redo with per-level launches
         fprintf(stderr, "[dipgenie_hip] team kernel reported code %u; falling back to per-level launches\n", team_err);
         team_failed = true;
         S.team_fallbacks++;
         goto retry_forward;
     }
-    S.last_team_size = team ? (int)ctl_host[0].team_count[(ctl_host[0].leader_xcc_plus1 - 1) & 7] : 0;
-    if (team && getenv("DG_DEBUG")) {
-        int nt = 0; int64_t nl = 0;
-        for (auto &sg : S.schedule) if (sg.team) { ++nt; nl += sg.end - sg.begin; }
-        fprintf(stderr, "[dipgenie_hip] schedule: %d team launches covering %lld of %d levels; team size %d of %u WGs; last team: %.3f ms, shader clock %.0f MHz\n", nt, (long long)nl,
-                S.L - 1, S.last_team_size, ctl_host[0].registered, ctl_host[0].t_real / 1e5, ctl_host[0].t_real ? 100.0 * ctl_host[0].t_cycles / ctl_host[0].t_real : 0.0);
-    }
-    if (team && getenv("DG_TEAM_PROF")) {
+    S.last_team_size = team_used ? (int)ctl_host[0].team_count[(ctl_host[0].leader_xcc_plus1 - 1) & 7] : 0;
+    if (team_used && getenv("DG_DEBUG"))
+        fprintf(stderr, "[dipgenie_hip] %d team launches; team size %d of %u WGs; first team: %.3f ms, shader clock %.0f MHz\n", n_team_launch,
+                S.last_team_size, ctl_host[0].registered, ctl_host[0].t_real / 1e5, ctl_host[0].t_real ? 100.0 * ctl_host[0].t_cycles / ctl_host[0].t_real : 0.0);
+    if (team_used && getenv("DG_TEAM_PROF")) {
         const TeamCtl &h = ctl_host[0];
-        const double nl = 1.0;
-        fprintf(stderr, "[dipgenie_hip] slot0 cycles: desc %.0f tasks %.0f drain %.0f sync1 %.0f barrier %.0f total %.0f | tables %.0f relax %.0f reduce %.0f store %.0f\n", h.phase[0] / nl, h.phase[1] / nl,
-                h.phase[2] / nl, h.phase[3] / nl, h.phase[4] / nl, h.phase[5] / nl, h.tphase[0] / nl, h.tphase[1] / nl, h.tphase[2] / nl, h.tphase[3] / nl);
+        fprintf(stderr, "[dipgenie_hip] slot0 cycles: desc %llu tasks %llu drain %llu sync1 %llu barrier %llu total %llu | tables %llu relax %llu reduce %llu store %llu\n",
+                h.phase[0], h.phase[1], h.phase[2], h.phase[3], h.phase[4], h.phase[5], h.tphase[0], h.tphase[1], h.tphase[2], h.tphase[3]);
     }
     DG_HIP(hipEventElapsedTime(&S.timing.delta_ms, S.ev[0], S.ev[1]));
     DG_HIP(hipEventElapsedTime(&S.timing.forward_ms, S.ev[1], S.ev[2]));
@@ -1145,6 +1226,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "team_max_tasks")) c->dp->team_max_tasks = v;
     else if (!strcmp(key, "team_min_levels")) c->dp->team_min_levels = v;
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
+    else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;
     else if (!strcmp(key, "max_blocks")) c->dp->max_blocks = v > 0 ? v : 2048;
     else { dgi::set_error("unknown option %s", key); return DG_ERR_ARG; }

@@ -149,6 +149,20 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             gpu_ctx.dp_set_option(k, v)
 
 
+@pytest.mark.parametrize("seg_cells", [1, 5000, 200000])
+def test_dp_segmented_lattice(gpu_ctx, seg_cells):
+    """checkpoint + recompute (lattices beyond HBM, BASELINE config 5): forced here with tiny segments; value, s_het,
+    edge lists and every level digest must not change"""
+    try:
+        gpu_ctx.dp_set_option("segment_cells", seg_cells)
+        for seed, kw in [(11, dict(max_width=14, n_levels=400, R=6)), (12, dict(max_width=45, n_levels=70, R=18, p_w1=0.5)),
+                         (13, dict(n_levels=2, R=2)), (14, dict(max_width=8, n_levels=3000, R=3, p_colour=0.3)), (15, dict(R=33, max_width=25, n_levels=90))]:
+            _dp_both(gpu_ctx, graphgen.random_levelized(8000 + seed, **kw))
+        _dp_both(gpu_ctx, capi.DpGraphArrays.load(os.path.join(HERE, "golden", "toy1_k5w3_R2.dpg")))
+    finally:
+        gpu_ctx.dp_set_option("segment_cells", 0)
+
+
 def test_dp_giant_indegree_uses_generic_path(gpu_ctx):
     """a vertex with in-degree > 64 (more than 64 haplotypes recombining into one vertex) leaves the fast path"""
     k = 90
