@@ -69,11 +69,18 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (one-GPU box): DG_BENCH_DEVICE pins every rank to one card, DG_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("DG_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["DG_BENCH_DEVICE"])
+    backend = os.environ.get("DG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---------------------------------------------------------------- build + inputs (untimed)
     import __graft_entry__ as ge
@@ -170,13 +177,15 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
-        t = torch.tensor([elapsed, sk_s, dp_s], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, sk_s, dp_s], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, sk_s, dp_s = (float(x) for x in t.tolist())
 
     if rank == 0:
         if e2e is not None and out.value != e2e["dp_value"]:
             raise SystemExit(f"bench DP value {out.value} != CLI DP value {e2e['dp_value']}")
+        if e2e is not None and int(gh.numel()) != int(e2e["spectrum"]):     # sharded sketch == single-process sketch of the CLI
+            raise SystemExit(f"sharded spectrum size {gh.numel()} != CLI spectrum size {e2e['spectrum']}")
         steps = args.steps
         cells = int(out.cells)
         tm = ctx.dp_timing()

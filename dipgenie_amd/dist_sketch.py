@@ -30,8 +30,16 @@ def _u64_as_i64(t):
     return t.view(torch.int64)
 
 
+def _coll_device(device):
+    """gloo (CPU tests / one-GPU rehearsals) moves data through host tensors; RCCL works on the device tensors"""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def allgather_runs(hash_t, count_t, device):
     """all-gather variable-length (hash uint64-as-int64, count int32) runs; returns concatenated tensors."""
+    out_device = device
+    device = _coll_device(device)
+    hash_t, count_t = hash_t.to(device), count_t.to(device)
     world = dist.get_world_size()
     n = torch.tensor([hash_t.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
@@ -46,7 +54,7 @@ def allgather_runs(hash_t, count_t, device):
     cs = [torch.empty_like(cp) for _ in range(world)]
     dist.all_gather(hs, hp)
     dist.all_gather(cs, cp)
-    return torch.cat([h[:s] for h, s in zip(hs, sizes)]), torch.cat([c[:s] for c, s in zip(cs, sizes)])
+    return torch.cat([h[:s] for h, s in zip(hs, sizes)]).to(out_device), torch.cat([c[:s] for c, s in zip(cs, sizes)]).to(out_device)
 
 
 def merge_runs_torch(hash_i64, count_i32):
@@ -86,7 +94,12 @@ class ShardedSketch:
                                                             h.numel(), counts.data_ptr()), "dg_sketch_count_dictionary_dev")
         self.ctx_sync()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == "gloo":
+                host = counts.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                counts.copy_(host)
+            else:
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         return counts
 
     def global_spectrum(self, h, c):
@@ -96,6 +109,8 @@ class ShardedSketch:
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return h, c
         hh, cc = allgather_runs(h, c, self.device)
+        if hh.is_cuda:
+            torch.cuda.synchronize(self.device)         # the collective ran on torch's stream, the merge runs on the ctx stream
         oh = torch.empty_like(hh)
         oc = torch.empty_like(cc)
         n = C.c_int64()
