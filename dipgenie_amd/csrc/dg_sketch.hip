@@ -36,8 +36,7 @@ struct Tile {
 };
 
 struct SketchState {
-    DevBuf d_bases, d_off, d_tiles, d_tile_cnt, d_tile_base, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n,
-        d_pos, d_kmers, d_out;
+    DevBuf d_bases, d_tiles, d_tile_cnt, d_tile_base, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
     dg_sketch_timing timing;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
