@@ -38,7 +38,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t grp_first, ngroups;                         // column groups (runs of <=64 in-edges covering whole columns)
     int32_t dead_first, ndead;                          // destination columns with no in-edge
     int64_t slot_first;                                 // first entry of this level in the 64-wide slot table
-    int32_t fast_ok, pad_;                              // 1: every in-degree <= 64 and sizes fit the fast kernel
+    int32_t fast_ok, nblocks;                           // fast kernel usable; number of 64-slot blocks (>= ngroups: giant columns take several)
 };
 
 struct TraceOut {
@@ -310,7 +310,9 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
 //   heavier rows fetch their in-edge list once, one per lane, and broadcast with readlane;
 // * the row's in-edges are processed two per step so two sets of RC loads are in flight;
 // * the segmented max runs only ceil(log2(max column in-degree of the group)) steps.
-// Levels with a vertex of in-degree > 64 (or sizes beyond the 2-D grid) use the generic kernel above.
+// A column with in-degree > 64 (more than 64 haplotypes recombining into one vertex) spans several blocks that one
+// wave walks in turn; rows of any in-degree fetch their in-edges 64 at a time.  Only sizes beyond the 2-D grid or
+// 2^28 in-edges per level fall back to the generic kernel above.
 // ---------------------------------------------------------------------------------------------
 struct FastArgs {
     const uint4 *rowrec;
@@ -341,6 +343,9 @@ __device__ __forceinline__ void relax_select(const int (&vals)[RC], int dl, uint
 // One task of the fast form: destination row i2, column group g, recombination chunk starting at r0.
 // AUX is the cache policy of the state loads: 0 = plain (per-level launches: the kernel boundary makes
 // the previous level visible), 16 = sc1 (team kernel: served by the XCD's L2, bypassing the CU's L1).
+// Lean variant: every in-degree of the level is <= 64 (no giant column blocks, row in-edges fit one per lane).
+// It is a separate function on purpose: a lone wave retires ~1 instruction per 4-8 cycles, and the extra loop
+// structure of the general variant below costs 25-30 % on the narrow levels that dominate MHC-scale graphs.
 template <int RC, bool DIGEST, int AUX, bool PROF = false>
 __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
                                            int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr) {
@@ -469,21 +474,169 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     if (PROF) { q4 = __builtin_amdgcn_s_memtime(); pp[0] += q1 - q0; pp[1] += q2 - q1; pp[2] += q3 - q2; pp[3] += q4 - q3; }
 }
 
+// General variant: any in-degree (see the notes on giant columns above); used for levels tagged fast_ok == 2.
+template <int RC, bool DIGEST, int AUX, bool PROF = false>
+__device__ __forceinline__ void sweep_task_general(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr) {
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+    if (PROF) q0 = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x & 63;
+    const int RP = A.RP;
+    const uint4 rr = A.rowrec[d.b0 + i2];                               // {eu0, du, pu0, pu1}
+    uint2 sl = A.slots[d.slot_first + (int64_t)g * 64 + lane];
+    // steps field: 0..6 = log2 steps of the segmented max; 15 = first block of a giant column (in-degree > 64: its
+    // in-edges fill several consecutive blocks, all walked by THIS wave); 14 = continuation block (nothing to do)
+    int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
+    if (steps == 14) return;
+    const int j2 = (sl.x != 0xFFFFFFFFu) ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
+    int nblk = 1;
+    if (steps == 15) {
+        const int col = __builtin_amdgcn_readfirstlane(j2);
+        nblk = ((int)A.rowrec[d.b0 + col].y + 63) >> 6;
+        steps = 6;
+    }
+    const bool has_delta = d.delta_off >= 0;
+    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const int dT = has_delta ? d.T : 0;
+    const int du = (int)rr.y;
+    if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
+    int bval[RC];
+    uint32_t bord[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+    const int64_t erow0 = (int64_t)(rr.x - d.in_base) * dT;
+    const int rowbytes = d.k * 4;
+    bool act = false;
+    // Source rows are r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
+    // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding; the select
+    // discards what is out of range, which lets every load be issued unconditionally, back to back.
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (blk > 0) sl = A.slots[d.slot_first + (int64_t)(g + blk) * 64 + lane];
+        const bool actb = sl.x != 0xFFFFFFFFu;
+        act |= actb;
+        const int j = (int)(sl.x & 0x7FFFu), wv = (int)((sl.x >> 15) & 1u);
+        const int dcol = has_delta ? (int)(sl.y & 0x0FFFFFFFu) : 0;
+        if (du <= 2) {
+            // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
+            if (actb && du > 0) {
+                const int ia = (int)(rr.z & 0x7FFFFFFFu), wa = (int)(rr.z >> 31) + wv;
+                const int ib = (int)(rr.w & 0x7FFFFFFFu), wb = (int)(rr.w >> 31) + wv;
+                const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
+                const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
+                int va[RC], vb[RC];
+                const int dla = (int)dm[erow0 + dcol];
+                int dlb = 0;
+#pragma unroll
+                for (int q = 0; q < RC; ++q) va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offa + q * rowbytes, 0, AUX);
+                if (du == 2) {
+                    dlb = (int)dm[erow0 + dT + dcol];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, AUX);
+                }
+                relax_select<RC>(va, dla, ord_word(ia, j, (int)(rr.z >> 31), wv), r0, wa, RP, bval, bord);
+                if (du == 2) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(rr.w >> 31), wv), r0, wb, RP, bval, bord);
+            }
+        } else {
+            // heavy rows (recombination fan-in): the in-edge list is fetched 64 at a time, one per lane, and broadcast
+            // with readlane; U in-edges per step -- all their loads (U deltas + U*RC values) go out back to back, then
+            // the selects run; (value, ord) max is associative and commutative, so the order inside a step is
+            // irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
+            constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : (RC >= 2 ? 8 : 16));
+            for (int c0 = 0; c0 < du; c0 += 64) {
+                const int dc = min(64, du - c0);
+                uint32_t mypu = 0;
+                if (lane < dc) mypu = A.in_edge[rr.x + c0 + lane];
+                for (int t = 0; t < dc; t += U) {
+                    uint32_t pu[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) pu[u] = (uint32_t)__builtin_amdgcn_readlane((int)mypu, min(t + u, dc - 1));
+                    if (actb) {
+                        int vals[U][RC], dl[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (t + u < dc) {                           // wave-uniform
+                                const int iu = (int)(pu[u] & 0x7FFFFFFFu), w = (int)(pu[u] >> 31) + wv;
+                                const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
+                                dl[u] = (int)dm[erow0 + (int64_t)(c0 + t + u) * dT + dcol];
+#pragma unroll
+                                for (int q = 0; q < RC; ++q) vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, off + q * rowbytes, 0, AUX);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (t + u < dc) {
+                                const int iu = (int)(pu[u] & 0x7FFFFFFFu), wu = (int)(pu[u] >> 31);
+                                relax_select<RC>(vals[u], dl[u], ord_word(iu, j, wu, wv), r0, wu + wv, RP, bval, bord);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (PROF) q2 = __builtin_amdgcn_s_memtime();
+    // segmented max over lanes with equal destination column (lanes of a column are adjacent)
+    for (int st = 0, sh = 1; st < steps; ++st, sh <<= 1) {
+        const int oj2 = __shfl_down(j2, sh);
+        const bool same = (lane + sh < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int ov = __shfl_down(bval[q], sh);
+            const uint32_t oo = (uint32_t)__shfl_down((int)bord[q], sh);
+            const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+            bval[q] = take ? ov : bval[q];
+            bord[q] = take ? oo : bord[q];
+        }
+    }
+    const int pj2 = __shfl_up(j2, 1);
+    const bool head = act & ((lane == 0) | (pj2 != j2));
+    unsigned long long dsum = 0;
+    if (PROF) q3 = __builtin_amdgcn_s_memtime();
+    if (head) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int r2 = r0 + q;
+            if (r2 < RP) {
+                const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                nxt[idx] = bval[q];
+                if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                if (DIGEST && bval[q] != NEG_INF) {
+                    const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
+                    dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
+                }
+            }
+        }
+    }
+    if (g == 0 && d.ndead > 0) {                                        // columns nobody owns: unreachable
+        for (int t = lane; t < d.ndead * RC; t += 64) {
+            const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
+            if (r0 + q < RP) {
+                const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
+                nxt[idx] = NEG_INF;
+                if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
+            }
+        }
+    }
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+    if (PROF) { q4 = __builtin_amdgcn_s_memtime(); pp[0] += q1 - q0; pp[1] += q2 - q1; pp[2] += q3 - q2; pp[3] += q4 - q3; }
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padded_base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)padded_base, 0, bytes, 0x00020000);
 }
 
 // per-level launch of the fast form: grid = (ceil(ngroups/4), k2 * nchunk), one task per wave
-template <int RC, bool DIGEST>
+template <int RC, bool DIGEST, bool GENERAL>
 __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl) {
     const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (g >= d.ngroups) return;                                         // wave-uniform; no block barrier below
+    if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
     const int nchunk = (A.RP + RC - 1) / RC;
     const int i2 = nchunk == 1 ? (int)blockIdx.y : (int)blockIdx.y / nchunk;
     const int r0 = nchunk == 1 ? 0 : ((int)blockIdx.y % nchunk) * RC;
     const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
-    sweep_task<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    if (GENERAL) sweep_task_general<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    else sweep_task<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -547,21 +700,21 @@ __global__ __launch_bounds__(512) void dp_team_kernel(FastArgs A, const LevelDes
         const __amdgpu_buffer_rsrc_t rs = state_rsrc(cur, A.buf_bytes);
         // A lone wave issues ~1 instruction per 4-8 cycles, so on narrow levels the RC-fold unrolled task IS the
         // critical path: split the recombination counts over more waves (chunks of 1 or 4) while the team has idle waves.
-        const int base_tasks = d.k2 * d.ngroups;
+        const int base_tasks = d.k2 * d.nblocks;
         if (base_tasks * A.RP <= n_waves) {
-            const int per_row = d.ngroups * A.RP, ntask = d.k2 * per_row;
+            const int per_row = d.nblocks * A.RP, ntask = d.k2 * per_row;
             for (int task = wave_id; task < ntask; task += n_waves) {
                 const int i2 = task / per_row, rem = task - i2 * per_row;
                 sweep_task<1, false, AUX, PROF>(A, d, rs, nxt, i2, rem / A.RP, rem % A.RP, lvl, tp);
             }
         } else if (RC > 4 && base_tasks * ((A.RP + 3) / 4) <= 2 * n_waves) {
-            const int nc4 = (A.RP + 3) / 4, per_row = d.ngroups * nc4, ntask = d.k2 * per_row;
+            const int nc4 = (A.RP + 3) / 4, per_row = d.nblocks * nc4, ntask = d.k2 * per_row;
             for (int task = wave_id; task < ntask; task += n_waves) {
                 const int i2 = task / per_row, rem = task - i2 * per_row;
                 sweep_task<4, false, AUX, PROF>(A, d, rs, nxt, i2, rem / nc4, (rem % nc4) * 4, lvl, tp);
             }
         } else {
-            const int per_row = d.ngroups * nchunk, ntask = d.k2 * per_row;
+            const int per_row = d.nblocks * nchunk, ntask = d.k2 * per_row;
             for (int task = wave_id; task < ntask; task += n_waves) {
                 const int i2 = task / per_row, rem = task - i2 * per_row;
                 const int g = nchunk == 1 ? rem : rem / nchunk;
@@ -810,33 +963,47 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         }
         d.ngroups = (int32_t)grp_begin.size() - d.grp_first;
         grp_begin.push_back(d.in_base + (uint32_t)d.T);          // sentinel: end of the level's in-edges
-        // 64-wide slot table of the fast kernel
+        // 64-wide slot table of the fast kernel: one block per group; a giant column (in-degree > 64) takes
+        // ceil(dv/64) consecutive blocks (first one tagged 15, the rest 14) and counts as that many "groups"
         d.slot_first = (int64_t)(slots.size() / 2);
         d.fast_ok = (d.T < (1 << 28)) ? 1 : 0;
+        int32_t n_blocks = 0;
         for (int gi = 0; gi < d.ngroups; ++gi) {
             const uint32_t gb0 = grp_begin[d.grp_first + gi], ge0 = grp_begin[d.grp_first + gi + 1];
-            if (ge0 - gb0 > 64) d.fast_ok = 0;                   // giant column: generic kernel
+            const bool giant = ge0 - gb0 > 64;
+            if (giant && d.fast_ok) d.fast_ok = 2;               // the general sweep variant
             uint32_t maxdv = 1;
-            for (uint32_t e = gb0; e < ge0 && e < gb0 + 64; ) {
-                const int c = in_dst[e] - d.b0;
-                const uint32_t dv = in_off[d.b0 + c + 1] - in_off[d.b0 + c];
-                maxdv = std::max(maxdv, dv);
-                e += dv;
-            }
+            if (!giant)
+                for (uint32_t e = gb0; e < ge0;) {
+                    const int cc = in_dst[e] - d.b0;
+                    const uint32_t dv = in_off[d.b0 + cc + 1] - in_off[d.b0 + cc];
+                    maxdv = std::max(maxdv, dv);
+                    e += dv;
+                }
             uint32_t steps = 0;
             while ((1u << steps) < std::min(maxdv, 64u)) ++steps;
-            for (uint32_t q = 0; q < 64; ++q) {
-                const uint32_t e = gb0 + q;
-                if (e < ge0) {
-                    const uint32_t pv = in_edge[e];
-                    slots.push_back((pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16));
-                    slots.push_back((e - d.in_base) | (steps << 28));
-                } else {
-                    slots.push_back(0xFFFFFFFFu);
-                    slots.push_back(steps << 28);
+            const uint32_t nb = giant ? (ge0 - gb0 + 63) / 64 : 1;
+            for (uint32_t bq = 0; bq < nb; ++bq) {
+                const uint32_t tag = giant ? (bq == 0 ? 15u : 14u) : steps;
+                for (uint32_t q = 0; q < 64; ++q) {
+                    const uint32_t e = gb0 + bq * 64 + q;
+                    if (e < ge0) {
+                        const uint32_t pv = in_edge[e];
+                        slots.push_back((pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16));
+                        slots.push_back((e - d.in_base) | (tag << 28));
+                    } else {
+                        slots.push_back(0xFFFFFFFFu);
+                        slots.push_back(tag << 28);
+                    }
                 }
             }
+            n_blocks += (int32_t)nb;
         }
+        if (n_blocks == 0) {                                     // level without in-edges: one all-padding block
+            for (int q = 0; q < 64; ++q) { slots.push_back(0xFFFFFFFFu); slots.push_back(0); }
+            n_blocks = 1;
+        }
+        d.nblocks = n_blocks;
         d.ndead = (int32_t)dead_cols.size() - d.dead_first;
         if (d.ngroups == 0) { d.ngroups = 1; grp_begin.push_back(d.in_base + (uint32_t)d.T); }   // level without in-edges: one empty group
         const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
@@ -951,7 +1118,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = S.d_ctrl.ensure(sizeof(TeamCtl) * TEAM_CTL_SLOTS)) return rc;
     S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
     S.all_fast = true;
-    for (int l = 1; l < L; ++l) if (!S.descs[l].fast_ok || (int64_t)S.descs[l].k2 * S.descs[l].ngroups * 5 >= ((int64_t)1 << 31)) S.all_fast = false;
+    for (int l = 1; l < L; ++l) if (!S.descs[l].fast_ok || (int64_t)S.descs[l].k2 * S.descs[l].nblocks * 5 >= ((int64_t)1 << 31)) S.all_fast = false;
     S.cap = 2 * (R + 8);                               // edge records of both paths
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
     if (int rc = S.d_path.ensure(4 * (size_t)L)) return rc;
@@ -1004,7 +1171,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed;
         S.schedule.clear();
         for (int l = lb; l < le;) {
-            auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok && (int64_t)d.k2 * d.ngroups <= S.team_max_tasks; };
+            auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok == 1 && (int64_t)d.k2 * d.nblocks <= S.team_max_tasks; };
             int e = l;
             if (narrow(l)) { while (e < le && narrow(e)) ++e; }
             const bool is_team = e - l >= S.team_min_levels;
@@ -1039,19 +1206,20 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                 if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
                     // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
                     // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
-                    const int64_t base = (int64_t)d.k2 * d.ngroups;
+                    const int64_t base = (int64_t)d.k2 * d.nblocks;
                     int rc = rc_sel;
                     if (S.adaptive_rc) {
-                        if (base * S.RP <= S.chip_waves) rc = 1;
-                        else if (base * ((S.RP + 1) / 2) <= S.chip_waves) rc = 2;
-                        else if (base * ((S.RP + 3) / 4) <= S.chip_waves) rc = 4;
-                        if (rc > rc_sel) rc = rc_sel;
+                        static const int cand[5] = {1, 2, 4, 8, 16};
+                        for (int q = 0; q < 5; ++q)
+                            if (cand[q] < rc_sel && base * ((S.RP + cand[q] - 1) / cand[q]) <= S.chip_waves) { rc = cand[q]; break; }
                     }
                     const int nch = (S.RP + rc - 1) / rc;
-                    const dim3 grid((unsigned)((d.ngroups + 3) / 4), (unsigned)(d.k2 * nch));
-#define DG_FAST(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG>), grid, dim3(256), 0, s, F, d, l)
+                    const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)(d.k2 * nch));
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, F, d, l); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, F, d, l); } while (0)
 #define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
-                                        case 8: DG_FAST(8, DG); break; case 19: DG_FAST(19, DG); break; default: DG_FAST(33, DG); break; } } while (0)
+                                        case 8: DG_FAST(8, DG); break; case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
+                                        default: DG_FAST(33, DG); break; } } while (0)
                     if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
 #undef DG_FAST_RC
 #undef DG_FAST
