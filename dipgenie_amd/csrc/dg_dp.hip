@@ -277,7 +277,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r2 < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                     nxt[idx] = bval[q];
-                    if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                    if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
                     if (DIGEST && bval[q] != NEG_INF) {
                         const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                         dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -292,7 +292,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r0 + q < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                     nxt[idx] = NEG_INF;
-                    if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
+                    if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
                 }
             }
         }
@@ -452,7 +452,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r2 < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                 nxt[idx] = bval[q];
-                if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
                 if (DIGEST && bval[q] != NEG_INF) {
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -466,7 +466,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                 nxt[idx] = NEG_INF;
-                if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
+                if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
             }
         }
     }
@@ -599,7 +599,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             if (r2 < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                 nxt[idx] = bval[q];
-                if (A.bp) A.bp[d.bp_off + idx] = bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q]);
+                if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
                 if (DIGEST && bval[q] != NEG_INF) {
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -613,7 +613,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                 nxt[idx] = NEG_INF;
-                if (A.bp) A.bp[d.bp_off + idx] = BP_NONE;
+                if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
             }
         }
     }
