@@ -51,7 +51,7 @@ struct DpState {
     int64_t want_digest = 0, use_fast = 1, use_team = 0, team_grid = 256, max_blocks = 1024, team_fallbacks = 0;
     int last_team_size = 0;
     bool all_fast = false;
-    int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 1, chip_waves = 8192;
+    int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 1, chip_waves = 8192, waves_per_block = 4;
     // lattice segments: destination levels [seg_begin[s], seg_begin[s+1]); one segment = whole lattice resident.
     // More than one = checkpoint + recompute (value-only pass, then each segment re-swept with back-pointers, last first).
     std::vector<int> seg_begin;
@@ -628,7 +628,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 // per-level launch of the fast form: grid = (ceil(ngroups/4), k2 * nchunk), one task per wave
 template <int RC, bool DIGEST, bool GENERAL>
 __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl) {
-    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
     const int nchunk = (A.RP + RC - 1) / RC;
     const int i2 = nchunk == 1 ? (int)blockIdx.y : (int)blockIdx.y / nchunk;
@@ -1214,9 +1214,10 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                             if (cand[q] < rc_sel && base * ((S.RP + cand[q] - 1) / cand[q]) <= S.chip_waves) { rc = cand[q]; break; }
                     }
                     const int nch = (S.RP + rc - 1) / rc;
-                    const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)(d.k2 * nch));
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, F, d, l); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, F, d, l); } while (0)
+                    const int wpb = (int)S.waves_per_block;               // waves (= slot blocks) per workgroup
+                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)(d.k2 * nch));
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l); } while (0)
 #define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
                                         case 8: DG_FAST(8, DG); break; case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
                                         default: DG_FAST(33, DG); break; } } while (0)
@@ -1395,6 +1396,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "team_min_levels")) c->dp->team_min_levels = v;
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
+    else if (!strcmp(key, "waves_per_block")) c->dp->waves_per_block = (v >= 1 && v <= 4) ? v : 4;
     else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;
     else if (!strcmp(key, "max_blocks")) c->dp->max_blocks = v > 0 ? v : 2048;
     else { dgi::set_error("unknown option %s", key); return DG_ERR_ARG; }
