@@ -197,6 +197,10 @@ class Context:
     def dp_set_option(self, key, value):
         _check(lib.dg_dp_set_option(self.h, key.encode(), int(value)), "dg_dp_set_option")
 
+    def dp_prealloc(self, nbytes=0):
+        """start reserving back-pointer lattice chunks in the background (nbytes <= 0: 60 % of the free HBM)"""
+        _check(lib.dg_dp_prealloc(self.h, int(nbytes)), "dg_dp_prealloc")
+
     def dp_load_graph(self, g):
         self._g = g
         st = g.as_struct()

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "dg_internal.hpp"
@@ -68,16 +70,28 @@ struct DpState {
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // background reservation of the back-pointer lattice (dg_dp_prealloc): a 100+ GB hipMalloc takes seconds
-    std::thread pre_thread;
-    void *pre_ptr = nullptr;
-    size_t pre_bytes = 0;
+    // The resident back-pointer lattice lives in a pool of equal chunks that a background thread allocates one by
+    // one (a 100+ GB hipMalloc takes seconds, more when another process has just freed HBM): reservation can start
+    // before the graph exists (dg_dp_prealloc) without starving the small allocations of the sketch stage, and the
+    // sweep starts on chunk 0 while later chunks are still being mapped.  Levels never straddle chunks.
+    struct Pool {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<void *> chunks;           // each chunk_cells * 4 bytes
+        size_t chunk_cells = (size_t)2 << 30;  // 8 GB
+        size_t target = 0;                     // chunks wanted
+        size_t cap_chunks = 0;                 // upper bound for reservations made before the graph is known
+        bool running = false, failed = false, paused = false;
+        std::thread th;
+    } pool;
+    std::vector<int> chunk_begin;              // destination levels [chunk_begin[c], chunk_begin[c+1]) live in chunk c
 };
 
 void dp_state_free(DpState *s) {
     if (!s) return;
-    if (s->pre_thread.joinable()) s->pre_thread.join();
-    if (s->pre_ptr) (void)hipFree(s->pre_ptr);
+    { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
+    if (s->pool.th.joinable()) s->pool.th.join();
+    for (void *q : s->pool.chunks) (void)hipFree(q);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -844,6 +858,62 @@ static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t s) {
     return DG_OK;
 }
 
+// Ask for `target` chunks (the latest request wins): starts the allocation thread if chunks are missing.  Chunks
+// already mapped beyond the target are kept (hipFree of 8 GB costs ~0.1 s) unless pool_trim is called.  Returns at once.
+static void pool_request(DpState &S, int device, size_t target) {
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    S.pool.target = std::max(target, S.pool.chunks.size());
+    if (S.pool.running || S.pool.chunks.size() >= S.pool.target) return;
+    if (S.pool.th.joinable()) { lk.unlock(); S.pool.th.join(); lk.lock(); }
+    S.pool.running = true;
+    S.pool.failed = false;
+    DpState *Sp = &S;
+    S.pool.th = std::thread([Sp, device]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            size_t bytes;
+            {
+                std::unique_lock<std::mutex> lk2(Sp->pool.mu);
+                Sp->pool.cv.wait(lk2, [&] { return !Sp->pool.paused; });
+                if (Sp->pool.chunks.size() >= Sp->pool.target) { Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
+                bytes = Sp->pool.chunk_cells * 4;
+            }
+            void *q = nullptr;
+            const hipError_t e = hipMalloc(&q, bytes);
+            std::unique_lock<std::mutex> lk2(Sp->pool.mu);
+            if (e != hipSuccess) { (void)hipGetLastError(); Sp->pool.failed = true; Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
+            Sp->pool.chunks.push_back(q);
+            Sp->pool.cv.notify_all();
+            lk2.unlock();
+            // HIP calls of other threads queue on a runtime lock this thread would otherwise win again at once
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    });
+}
+// hipMalloc calls queue behind the one in flight, so a caller with many small allocations to make (dp_load) holds
+// the pool thread between chunks meanwhile
+struct PoolPause {
+    DpState &S;
+    explicit PoolPause(DpState &s) : S(s) { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.paused = true; }
+    ~PoolPause() { { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.paused = false; } S.pool.cv.notify_all(); }
+};
+// free chunks beyond `keep` (and stop asking for more than that)
+static void pool_trim(DpState &S, size_t keep) {
+    { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.target = std::min(S.pool.target, keep); }
+    if (S.pool.th.joinable()) S.pool.th.join();               // it stops at the next chunk boundary
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    while (S.pool.chunks.size() > keep) { (void)hipFree(S.pool.chunks.back()); S.pool.chunks.pop_back(); }
+    S.pool.running = false;
+}
+// drop every chunk (used before a differently sized pool or the segmented mode takes the memory)
+static void pool_clear(DpState &S) { pool_trim(S, 0); }
+// wait until chunk c exists; nullptr if the allocation failed
+static void *pool_wait(DpState &S, size_t c) {
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    S.pool.cv.wait(lk, [&] { return S.pool.chunks.size() > c || S.pool.failed || !S.pool.running; });
+    return S.pool.chunks.size() > c ? S.pool.chunks[c] : nullptr;
+}
+
 static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
@@ -1034,26 +1104,35 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (nblk >= (int64_t)1 << 31) { set_error("delta grid too large"); return DG_ERR_UNSUPPORTED; }
 
     lap("descs + groups + slots");
-    // adopt the background reservation, if any
-    if (S.pre_thread.joinable()) S.pre_thread.join();
-    if (S.pre_ptr) {
-        if (S.pre_bytes > S.d_bp.bytes) { S.d_bp.release(); S.d_bp.p = S.pre_ptr; S.d_bp.bytes = S.pre_bytes; }
-        else (void)hipFree(S.pre_ptr);
-        S.pre_ptr = nullptr; S.pre_bytes = 0;
-    }
-    lap("join prealloc");
-    // memory budget and lattice segmentation
+    // memory budget, lattice chunking / segmentation
     const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_entries * 2;
     size_t free_b = 0, total_b = 0;
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t have = free_b + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes + S.d_ckpt.bytes;
+    size_t pool_bytes;
+    { std::unique_lock<std::mutex> lk(S.pool.mu); pool_bytes = S.pool.chunks.size() * S.pool.chunk_cells * 4; }
+    const size_t have = free_b + pool_bytes + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes + S.d_ckpt.bytes;
     const size_t fixed = st_bytes + dl_bytes + 64 * (size_t)nV + ((size_t)2 << 30);     // state, delta, tables, slack
     if (fixed > have) {
         set_error("graph needs %.1f GB of HBM for state/delta/tables but only %.1f GB is free", fixed / 1e9, have / 1e9);
         return DG_ERR_OOM;
     }
+    // resident mode: levels packed into equal chunks (a level never straddles two)
+    size_t chunk_cells = S.pool.chunk_cells;
+    if ((size_t)S.max_level_cells > chunk_cells) chunk_cells = (size_t)S.max_level_cells;
+    S.chunk_begin.assign(1, 1);
+    {
+        size_t acc = 0;
+        for (int l = 1; l < L; ++l) {
+            const size_t ncell = (size_t)S.descs[l].k2 * S.descs[l].k2 * S.RP;
+            if (acc > 0 && acc + ncell > chunk_cells) { S.chunk_begin.push_back(l); acc = 0; }
+            acc += ncell;
+        }
+        S.chunk_begin.push_back(L);
+    }
+    const size_t n_chunks = S.chunk_begin.size() - 1;
+    const size_t resident_bytes = n_chunks == 1 ? (size_t)S.total_cells * 4 : n_chunks * chunk_cells * 4;
+    bool segmented = resident_bytes + fixed > have || S.segment_cells > 0;
     int64_t seg_cap_cells = (int64_t)((have - fixed) / 4);                            // back-pointer cells that fit
-    bool segmented = S.total_cells > seg_cap_cells || S.segment_cells > 0;
     if (segmented) {
         // keep half of the room for the checkpoints; a segment must hold at least its largest level
         seg_cap_cells = S.segment_cells > 0 ? S.segment_cells : seg_cap_cells / 2;
@@ -1062,11 +1141,11 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.seg_begin.assign(1, 1);
     S.ckpt_off.assign(1, 0);
     int64_t max_seg_cells = 0, ckpt_cells = 0;
-    {
+    if (segmented) {
         int64_t acc = 0;
         for (int l = 1; l < L; ++l) {
             const int64_t ncell = (int64_t)S.descs[l].k2 * S.descs[l].k2 * S.RP;
-            if (segmented && acc > 0 && acc + ncell > seg_cap_cells) {
+            if (acc > 0 && acc + ncell > seg_cap_cells) {
                 S.seg_begin.push_back(l);
                 S.ckpt_off.push_back(ckpt_cells);
                 ckpt_cells += (int64_t)S.descs[l].k * S.descs[l].k * S.RP;            // state of level l-1
@@ -1076,16 +1155,36 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             acc += ncell;
         }
         max_seg_cells = std::max(max_seg_cells, acc);
-        S.seg_begin.push_back(L);
     }
-    const size_t bp_bytes = (size_t)max_seg_cells * 4, ck_bytes = (size_t)ckpt_cells * 4;
-    if (bp_bytes + ck_bytes + fixed > have) {
-        set_error("segmented lattice needs %.1f GB (+%.1f GB checkpoints) but only %.1f GB of HBM is free", bp_bytes / 1e9, ck_bytes / 1e9, have / 1e9);
-        return DG_ERR_OOM;
+    S.seg_begin.push_back(L);
+    const size_t bp_bytes = segmented ? (size_t)max_seg_cells * 4 : 0, ck_bytes = (size_t)ckpt_cells * 4;
+    if (segmented) {
+        pool_clear(S);                                        // the segment buffer takes the room instead
+        if (bp_bytes + ck_bytes + fixed > have) {
+            set_error("segmented lattice needs %.1f GB (+%.1f GB checkpoints) but only %.1f GB of HBM is free", bp_bytes / 1e9, ck_bytes / 1e9, have / 1e9);
+            return DG_ERR_OOM;
+        }
+        if (dbg)
+            fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_cells * 4 / 1e9,
+                    S.seg_begin.size() - 1, bp_bytes / 1e9, ck_bytes / 1e9);
+    } else {
+        S.d_bp.release();
+        if (n_chunks == 1 && (size_t)S.total_cells < S.pool.chunk_cells / 8) {
+            // small lattice: one exact allocation instead of an 8 GB chunk
+            pool_clear(S);
+            { std::unique_lock<std::mutex> lk(S.pool.mu); }
+            if (int rc = S.d_bp.ensure((size_t)S.total_cells * 4)) return rc;
+        } else {
+            if (chunk_cells != S.pool.chunk_cells) { pool_clear(S); S.pool.chunk_cells = chunk_cells; }
+            // surplus chunks of an over-estimated reservation stay unless the other buffers need their room
+            const size_t mapped = pool_bytes / (chunk_cells * 4);
+            if (mapped > n_chunks && free_b < fixed) pool_trim(S, n_chunks);
+            pool_request(S, c->device, n_chunks);        // returns at once; dp_run waits chunk by chunk
+            if (dbg) fprintf(stderr, "[dipgenie_hip] lattice: %zu chunks of %.1f GB, %zu mapped so far\n", n_chunks, chunk_cells * 4 / 1e9, mapped);
+        }
     }
-    if (dbg && S.seg_begin.size() > 2)
-        fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_cells * 4 / 1e9,
-                S.seg_begin.size() - 1, bp_bytes / 1e9, ck_bytes / 1e9);
+    PoolPause pause(S);                                         // until the allocations below are done
+    lap("plan lattice");
     hipStream_t s = c->stream;
     if (int rc = upload(S.d_descs, S.descs.data(), sizeof(LevelDesc) * L, s)) return rc;
     if (int rc = upload(S.d_in_off, in_off.data(), 4 * in_off.size(), s)) return rc;
@@ -1104,7 +1203,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     lap("table uploads");
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
-    if (int rc = S.d_bp.ensure(bp_bytes)) return rc;
+    if (segmented) { if (int rc = S.d_bp.ensure(bp_bytes)) return rc; }
     if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
     if (int rc = S.d_chain.ensure(sizeof(ChainState))) return rc;
     S.pad_front = 2 * (int64_t)max_k;
@@ -1128,7 +1227,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     memset(&S.timing, 0, sizeof S.timing);
     S.timing.edge_pairs = S.edge_pairs;
     S.timing.colour_entries = S.colour_entries;
-    S.timing.state_bytes = st_bytes; S.timing.bp_bytes = bp_bytes; S.timing.delta_bytes = dl_bytes;
+    S.timing.state_bytes = st_bytes; S.timing.bp_bytes = segmented ? bp_bytes : resident_bytes; S.timing.delta_bytes = dl_bytes;
     (void)dtrans;
     S.loaded = true;
     return DG_OK;
@@ -1244,6 +1343,14 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     };
     const int n_seg = (int)S.seg_begin.size() - 1;
 
+    // Launches issued while the pool thread is still mapping chunks would each queue behind a multi-GB hipMalloc,
+    // so there is nothing to overlap: wait for the whole lattice first.
+    if (n_seg == 1 && !S.d_bp.p) {
+        const double tw0 = wall_s();
+        const size_t n_chunks = S.chunk_begin.size() - 1;
+        if (!pool_wait(S, n_chunks - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_cells * 4 / 1e9); return DG_ERR_OOM; }
+        if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: waited %.3f s for lattice chunks\n", wall_s() - tw0);
+    }
 retry_forward:
     n_launch = 0; team_used = false; team_err = 0;
     DG_HIP(hipEventRecord(S.ev[0], s));
@@ -1257,11 +1364,22 @@ retry_forward:
     if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
     hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
     if (n_seg == 1) {
-        // whole lattice resident: one sweep with back-pointers, one chain walk
-        if (int rc = sweep_range(1, S.L, S.d_bp.as<uint32_t>())) return rc;
+        // whole lattice resident (in chunks): one sweep with back-pointers, then the chain walk chunk by chunk, last first
+        const int n_chunks = S.d_bp.p ? 1 : (int)S.chunk_begin.size() - 1;
+        std::vector<uint32_t *> biased(n_chunks);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            uint32_t *base = S.d_bp.p ? S.d_bp.as<uint32_t>() : (uint32_t *)pool_wait(S, (size_t)ch);
+            if (!base) { set_error("back-pointer lattice: hipMalloc of chunk %d (%.1f GB) failed", ch, S.pool.chunk_cells * 4 / 1e9); return DG_ERR_OOM; }
+            biased[ch] = base - S.descs[lb].bp_off;
+            if (int rc = sweep_range(lb, le, biased[ch])) return rc;
+        }
         DG_HIP(hipEventRecord(S.ev[2], s));
-        hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, S.L - 1, 1, S.RP, S.R, S.d_bp.as<uint32_t>(),
-                           state_ptr(S.L - 1), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+        for (int ch = n_chunks - 1; ch >= 0; --ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch],
+                               ch == n_chunks - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+        }
     } else {
         // pass 1: values only, keeping the state in front of every segment
         const bool dig = S.want_digest;
@@ -1359,19 +1477,14 @@ extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
     if (int rc = dgi::bind(c)) return rc;
     if (!c->dp) c->dp = new dgi::DpState();
     dgi::DpState &S = *c->dp;
-    if (S.pre_thread.joinable() || S.pre_ptr) return DG_OK;           // already reserving
-    size_t free_b = 0, total_b = 0;
-    DG_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t want = bytes > 0 ? std::min((size_t)bytes, (size_t)(0.6 * (double)free_b)) : (size_t)(0.6 * (double)free_b);
-    if (want + ((size_t)8 << 30) > free_b) want = free_b > ((size_t)8 << 30) ? free_b - ((size_t)8 << 30) : 0;
-    if (want <= S.d_bp.bytes || want == 0) return DG_OK;
-    const int dev = c->device;
-    dgi::DpState *Sp = &S;
-    S.pre_thread = std::thread([dev, want, Sp]() {
-        if (hipSetDevice(dev) != hipSuccess) return;
-        void *p = nullptr;
-        if (hipMalloc(&p, want) == hipSuccess) { Sp->pre_ptr = p; Sp->pre_bytes = want; }
-    });
+    const size_t chunk_bytes = S.pool.chunk_cells * 4;
+    if (S.pool.cap_chunks == 0) {          // first call only: later ones may arrive while chunks are being mapped
+        size_t free_b = 0, total_b = 0;
+        DG_HIP(hipMemGetInfo(&free_b, &total_b));
+        S.pool.cap_chunks = std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / chunk_bytes);
+    }
+    const size_t want_chunks = bytes > 0 ? std::min(((size_t)bytes + chunk_bytes - 1) / chunk_bytes, S.pool.cap_chunks) : S.pool.cap_chunks;
+    dgi::pool_request(S, c->device, want_chunks);   // whole chunks; returns immediately
     return DG_OK;
 }
 extern "C" int dg_dp_get_timing(dg_ctx *c, dg_dp_timing *t) {
@@ -1396,6 +1509,11 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "team_min_levels")) c->dp->team_min_levels = v;
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
+    else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (default 2^31 cells = 8 GB)
+        if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
+        dgi::pool_clear(*c->dp);
+        c->dp->pool.chunk_cells = (size_t)v;
+    }
     else if (!strcmp(key, "waves_per_block")) c->dp->waves_per_block = (v >= 1 && v <= 4) ? v : 4;
     else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;
     else if (!strcmp(key, "max_blocks")) c->dp->max_blocks = v > 0 ? v : 2048;

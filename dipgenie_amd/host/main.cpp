@@ -21,7 +21,7 @@ static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint6
 }
 static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
 static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reservation (4 B/cell) with the host stages
-    const double bytes = 4.0 * (double)est_cells * 1.5;
+    const double bytes = 4.0 * (double)est_cells;     // a low estimate is harmless: the rest is mapped during the sweep
     if (bytes >= 4e9) dg_dp_prealloc((dg_ctx *)c, bytes > 8e18 ? 0 : (int64_t)bytes);   // small lattices allocate instantly anyway
 }
 

@@ -210,8 +210,10 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     if (opt.ploidy == 2 && be.hint_dp_soon) {       // device work of the sketches is done: let the device side reserve the DP lattice
         size_t max_path = 0;
         for (auto &pw : paths) max_path = std::max(max_path, pw.size());
-        const double kk = 4.0 * (double)num_walks;  // level width ~ walks x (chain + recombination + dummy vertices)
-        be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, (double)max_path * kk * kk * (opt.R + 1)));
+        // Generous on purpose (levels ~ 2.5 x path steps, width ~ 5 x walks: chain + recombination + dummy vertices):
+        // reserving too much costs nothing once the exact figure (diploid(), below) stops it, too little stalls the DP.
+        const double kk = 5.0 * (double)num_walks;
+        be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, 2.5 * (double)max_path * kk * kk * (opt.R + 1)));
     }
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
@@ -880,6 +882,11 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     double t0 = now_s();
     const int L = (int)g.level_off.size() - 1;
     const int nV = g.n;
+    if (be.hint_dp_soon) {                                             // level widths are final: the exact lattice size
+        double cells = 0;
+        for (int l = 1; l < L; ++l) { const double kw = (double)(g.level_off[l + 1] - g.level_off[l]); cells += kw * kw; }
+        be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, cells * (opt.R + 1)));
+    }
     if (!opt.quiet && g.level_off[1] - g.level_off[0] > 1) std::cout << "There is more than one source on level zero!" << std::endl;
     // the flat graph already is the dg_dp_graph layout (vertex ids are level-sorted: ExpandedGraph.hpp:360-407)
     dpg = DpGraphStorage();

@@ -29,7 +29,7 @@ struct Backend {     // same signatures as the C ABI, plus an opaque ctx
     int (*sketch_haplotype)(void *, const char *, int64_t, int, int, uint64_t **, int64_t **, int64_t *) = nullptr;
     int (*dp_solve_diploid)(void *, const dg_dp_graph *, dg_dp_result *) = nullptr;
     void (*free_buf)(void *) = nullptr;
-    void (*hint_dp_soon)(void *, int64_t est_cells) = nullptr;   // optional: the DP will be called later in this run with roughly est_cells cells
+    void (*hint_dp_soon)(void *, int64_t est_cells) = nullptr;   // optional, may be called repeatedly (latest wins): the DP will run later with about est_cells cells
     const char *(*last_error)() = nullptr;
 };
 

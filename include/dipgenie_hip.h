@@ -74,8 +74,10 @@ typedef struct dg_dp_timing {         /* HIP-event times of the last dg_dp_run, 
     uint64_t state_bytes, bp_bytes, delta_bytes;   /* device allocations */
 } dg_dp_timing;
 
-/* optional: start reserving the back-pointer lattice in a background thread (bytes <= 0: 60 % of the free
- * HBM). A 100+ GB hipMalloc takes seconds; the CLI overlaps it with the host stages. */
+/* optional: reserve about `bytes` of back-pointer lattice (bytes <= 0: 60 % of the free HBM) in a background
+ * thread, in 8 GB chunks; may be called again with a better figure (the latest call wins, chunks already mapped
+ * are kept). Mapping 100+ GB takes seconds and stalls every other HIP call meanwhile, so the CLI issues it where
+ * only host work follows; dg_dp_load_graph adopts the chunks and dg_dp_run waits for any still missing. */
 int dg_dp_prealloc(dg_ctx *, int64_t bytes);
 int dg_dp_load_graph(dg_ctx *, const dg_dp_graph *);   /* validate + upload + build in-CSR; resident until next load */
 int dg_dp_run(dg_ctx *, dg_dp_result *);               /* all kernels on the resident graph; synchronises */

@@ -163,6 +163,23 @@ def test_dp_segmented_lattice(gpu_ctx, seg_cells):
         gpu_ctx.dp_set_option("segment_cells", 0)
 
 
+@pytest.mark.parametrize("chunk_cells", [1, 3000, 150000])
+def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
+    """the resident back-pointer lattice is a pool of chunks mapped by a background thread while the sweep runs;
+    forced here with tiny chunks (one level per chunk at 1): results and level digests must not change, also when
+    the same context is reused for graphs that need more / fewer chunks, and with a reservation made up front"""
+    try:
+        gpu_ctx.dp_set_option("lattice_chunk_cells", chunk_cells)
+        gpu_ctx.dp_prealloc(chunk_cells * 4 * 3)
+        for seed, kw in [(21, dict(max_width=14, n_levels=400, R=6)), (22, dict(max_width=45, n_levels=70, R=18, p_w1=0.5)),
+                         (23, dict(n_levels=2, R=2)), (24, dict(max_width=8, n_levels=3000, R=3, p_colour=0.3)), (25, dict(R=33, max_width=25, n_levels=90)),
+                         (26, dict(max_width=6, n_levels=40, R=4))]:
+            _dp_both(gpu_ctx, graphgen.random_levelized(8100 + seed, **kw))
+        _dp_both(gpu_ctx, capi.DpGraphArrays.load(os.path.join(HERE, "golden", "toy1_k5w3_R2.dpg")))
+    finally:
+        gpu_ctx.dp_set_option("lattice_chunk_cells", 1 << 31)
+
+
 def test_dp_giant_indegree_uses_generic_path(gpu_ctx):
     """a vertex with in-degree > 64 (more than 64 haplotypes recombining into one vertex) leaves the fast path"""
     k = 90
