@@ -48,6 +48,28 @@ def truncated_graph(g, target_cells):
                          het_off=g.het_off[: nv + 1], het_col=g.het_col[: int(g.het_off[nv])]), P
 
 
+def usable_cores(cap=32):
+    """CPU threads this process may really use: affinity mask, clipped by the cgroup CPU quota (a GPU box hands one GPU
+    a 16-CPU share of a larger host; oversubscribing it makes OpenMP spin loops fight the HIP runtime's threads)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(cap, n))
+
+
 def reference_baseline(cache):
     """The reference's own OpenMP solver (oracle/_ref/DipGenie_ref, built by __graft_entry__.build() from
     /root/reference where that exists) timed on this node's host cores on BASELINE configs[1]'s graph
@@ -59,7 +81,7 @@ def reference_baseline(cache):
     gfa, reads = (os.path.join(ROOT, "tests", "data", n) for n in ("MHC_4.gfa.gz", "CHM13_reads.fq.gz"))
     if not (os.path.exists(exe) and os.path.exists(gfa) and os.path.exists(reads)):
         return None
-    cores = min(32, len(os.sched_getaffinity(0)))
+    cores = usable_cores()
     out_fa = os.path.join(cache, "ref_mhc4_p2.fa")
     os.makedirs(cache, exist_ok=True)
     t0 = time.perf_counter()
@@ -147,7 +169,7 @@ def main():
         # one end-to-end run of the drop-in CLI (HIP sketch + HIP DP): produces the levelized DP graph
         # (.dpg) that the timed steps re-solve, and the end-to-end seconds with per-stage breakdown.
         t0 = time.time()
-        subprocess.run([cli, "-t", str(min(32, os.cpu_count() or 8)), "-p2", f"-R{R}", "-g", gfa, "-r", reads_path, "-o", pre + ".fa",
+        subprocess.run([cli, "-t", str(usable_cores()), "-p2", f"-R{R}", "-g", gfa, "-r", reads_path, "-o", pre + ".fa",
                         "-D", pre, "-J", pre + ".json", "-G", str(local_rank)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         e2e = json.load(open(pre + ".json"))
         e2e["wall_s"] = time.time() - t0
@@ -245,6 +267,18 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes / n_launch, "launches": n_launch, "avg_launch_ms": 1e3 * fwd_s / n_launch,
                          "dependency_chain_levels": g.n_levels},
         }
+        # HBM traffic of the same kernels on the same workload, from the committed PMC passes (rocprofv3 cannot run
+        # inside this process): bytes per launch, upper end of the calibrated range
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_mhc24_traffic.json")
+        if args.workload == "mhc24" and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            if pmc.get("launches") == n_launch:
+                line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]["high"]
+                line["roofline"]["traffic_unit"] = "bytes/launch"
+                line["roofline"]["traffic_range"] = [pmc["hbm_bytes_per_launch"]["low"], pmc["hbm_bytes_per_launch"]["high"]]
+                line["roofline"]["traffic_source"] = ("profiles/r01_pmc_mhc24_traffic.json: WRITE_SIZE + calibrated FETCH_SIZE of all "
+                                                      f"{n_launch} sweep launches of one DP pass on this workload (separate --pmc passes)")
         if e2e is not None:
             line["end_to_end_s"] = e2e["wall_s"]
             line["end_to_end_stages_s"] = e2e.get("stages")

@@ -59,6 +59,7 @@ struct DpState {
     std::vector<int> seg_begin;
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     int64_t segment_cells = 0;                          // option: force segments of at most this many cells (tests)
+    int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
     std::vector<Segment> schedule;
     size_t state_alloc_bytes = 0;
@@ -1332,6 +1333,8 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
 #undef DG_SWEEP
                 }
                 ++n_launch;
+                // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
+                if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
             }
         }
         return DG_OK;
@@ -1509,6 +1512,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "team_min_levels")) c->dp->team_min_levels = v;
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
+    else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
     else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (default 2^31 cells = 8 GB)
         if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
         dgi::pool_clear(*c->dp);

@@ -7,6 +7,7 @@ from dipgenie_amd import capi
 ctx = capi.Context(0)
 g = capi.DpGraphArrays.load(sys.argv[1])
 ctx.dp_set_option("fast", int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+if os.environ.get("DG_SYNC_EVERY"): ctx.dp_set_option("sync_every", int(os.environ["DG_SYNC_EVERY"]))
 ctx.dp_load_graph(g)
 for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     out = ctx.dp_run()
