@@ -59,6 +59,7 @@ struct DpState {
     std::vector<int> seg_begin;
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     int64_t segment_cells = 0;                          // option: force segments of at most this many cells (tests)
+    int64_t host_threads = 16;                          // option: threads used by dg_dp_load_graph's table construction
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
     std::vector<Segment> schedule;
@@ -932,174 +933,274 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     DpState &S = *c->dp;
     S.loaded = false;
     S.nV = nV; S.L = L; S.R = R; S.RP = R + 1;
-    std::vector<int32_t> level_of(nV);
-    int max_k = 0;
-    for (int l = 0; l < L; ++l) {
-        const int k = g->level_off[l + 1] - g->level_off[l];
-        if (k <= 0) { set_error("level %d is empty", l); return DG_ERR_ARG; }
-        max_k = std::max(max_k, k);
-        for (int v = g->level_off[l]; v < g->level_off[l + 1]; ++v) level_of[v] = l;
+    // Host-side table construction runs on a few std::threads over contiguous LEVEL ranges balanced by vertex count
+    // (no OpenMP in this library: the caller may bring its own runtime).  Edges only go from level l to l + 1 and
+    // vertex ids are level-sorted, so a range of source levels owns the in-edge lists of the next levels' vertices.
+    const int NT = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)S.host_threads, (int64_t)std::thread::hardware_concurrency(), (int64_t)L / 64 + 1}));
+    std::vector<int> lcut(NT + 1, L);                          // thread t owns levels [lcut[t], lcut[t+1])
+    lcut[0] = 0;
+    for (int t = 1; t < NT; ++t) {
+        const int32_t want = (int32_t)((int64_t)nV * t / NT);
+        lcut[t] = (int)(std::upper_bound(g->level_off, g->level_off + L + 1, want) - g->level_off) - 1;
+        lcut[t] = std::min(std::max(lcut[t], lcut[t - 1]), L);
     }
+    std::vector<std::string> terr(NT);
+    std::vector<int> trc(NT, DG_OK);
+    auto run_threads = [&](auto &&fn) {                        // fn(t): returns nothing; errors through tfail
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; ++t) th.emplace_back([&, t] { fn(t); });
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    auto tfail = [&](int t, int rc, const char *fmt, auto... a) {
+        if (trc[t] != DG_OK) return;
+        char buf[256];
+        snprintf(buf, sizeof buf, fmt, a...);
+        terr[t] = buf; trc[t] = rc;
+    };
+    auto first_error = [&]() -> int {
+        for (int t = 0; t < NT; ++t) if (trc[t] != DG_OK) { set_error("%s", terr[t].c_str()); return trc[t]; }
+        return DG_OK;
+    };
+    for (int l = 0; l < L; ++l)
+        if (g->level_off[l + 1] <= g->level_off[l]) { set_error("level %d is empty", l); return DG_ERR_ARG; }
+    std::vector<int32_t> level_of(nV);
+    std::vector<int> tmax_k(NT, 0);
+    run_threads([&](int t) {
+        for (int l = lcut[t]; l < lcut[t + 1]; ++l) {
+            tmax_k[t] = std::max(tmax_k[t], g->level_off[l + 1] - g->level_off[l]);
+            for (int v = g->level_off[l]; v < g->level_off[l + 1]; ++v) level_of[v] = l;
+        }
+    });
+    int max_k = 0;
+    for (int t = 0; t < NT; ++t) max_k = std::max(max_k, tmax_k[t]);
     if (max_k > MAX_K) { set_error("level width %d exceeds the supported %d", max_k, MAX_K); return DG_ERR_UNSUPPORTED; }
+    if (g->out_off[0] != 0) { set_error("out_off must start at 0"); return DG_ERR_ARG; }
+    for (int t = 1; t <= NT; ++t) {                            // monotone at the range seams (inside: checked by the owner)
+        const int v = lcut[t] < L ? g->level_off[lcut[t]] : nV;
+        if (g->out_off[v] < 0) { set_error("out_off negative at %d", v); return DG_ERR_ARG; }
+    }
     const int64_t E = g->out_off[nV];
-    if (E >= (int64_t)1 << 31) { set_error("too many edges (%lld)", (long long)E); return DG_ERR_UNSUPPORTED; }
+    if (E < 0 || E >= (int64_t)1 << 31) { set_error("unsupported number of edges (%lld)", (long long)E); return DG_ERR_UNSUPPORTED; }
     // in-CSR: in-edges of every vertex sorted by (source position asc, adjacency order asc)
     std::vector<uint32_t> in_off((size_t)nV + 1, 0), in_edge((size_t)E);
     std::vector<int32_t> in_dst((size_t)E);
-    for (int u = 0; u < nV; ++u) {
-        if (g->out_off[u + 1] < g->out_off[u]) { set_error("out_off not monotone at %d", u); return DG_ERR_ARG; }
-        for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) {
-            const int v = g->out_dst[e];
-            if (v < 0 || v >= nV || level_of[v] != level_of[u] + 1) {
-                set_error("edge %d->%d does not go to the next level", u, v); return DG_ERR_ARG;
+    run_threads([&](int t) {
+        const int va = g->level_off[lcut[t]], vb = lcut[t + 1] < L ? g->level_off[lcut[t + 1]] : nV;
+        for (int u = va; u < vb; ++u) {
+            if (g->out_off[u + 1] < g->out_off[u] || g->out_off[u + 1] > E) { tfail(t, DG_ERR_ARG, "out_off not monotone at %d", u); return; }
+            for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) {
+                const int v = g->out_dst[e];
+                if (v < 0 || v >= nV || level_of[v] != level_of[u] + 1) { tfail(t, DG_ERR_ARG, "edge %d->%d does not go to the next level", u, v); return; }
+                if (g->out_w[e] > 1) { tfail(t, DG_ERR_ARG, "edge weight %d > 1", (int)g->out_w[e]); return; }
+                in_off[v + 1]++;                               // v lies in a level this thread owns the sources of
             }
-            if (g->out_w[e] > 1) { set_error("edge weight %d > 1", (int)g->out_w[e]); return DG_ERR_ARG; }
-            in_off[v + 1]++;
         }
-    }
+    });
+    if (int rc = first_error()) return rc;
     for (int v = 0; v < nV; ++v) in_off[v + 1] += in_off[v];
-    {
-        std::vector<uint32_t> fill(in_off.begin(), in_off.end() - 1);
-        for (int u = 0; u < nV; ++u) {
+    run_threads([&](int t) {
+        const int va = g->level_off[lcut[t]], vb = lcut[t + 1] < L ? g->level_off[lcut[t + 1]] : nV;
+        // destinations of this range: the vertices of levels [lcut[t] + 1, lcut[t+1] + 1)
+        const int da = lcut[t] + 1 <= L ? g->level_off[std::min(lcut[t] + 1, L)] : nV;
+        const int db = lcut[t + 1] + 1 <= L ? g->level_off[std::min(lcut[t + 1] + 1, L)] : nV;
+        std::vector<uint32_t> fill(in_off.begin() + da, in_off.begin() + db);
+        for (int u = va; u < vb; ++u) {
             const uint32_t pos = (uint32_t)(u - g->level_off[level_of[u]]);
             for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) {
                 const int v = g->out_dst[e];
-                const uint32_t slot = fill[v]++;
+                const uint32_t slot = fill[v - da]++;
                 in_edge[slot] = pos | ((uint32_t)g->out_w[e] << 31);
                 in_dst[slot] = v;
             }
         }
-    }
-    for (int v = 0; v < nV; ++v)      // parallel edges must carry equal weights (always true for graphs built by
-        for (uint32_t e = in_off[v] + 1; e < in_off[v + 1]; ++e)   // Approximator::solve)
-            if ((in_edge[e] & 0x7FFFFFFFu) == (in_edge[e - 1] & 0x7FFFFFFFu) && in_edge[e] != in_edge[e - 1]) {
-                set_error("parallel edges with different weights into vertex %d: tie order would be schedule dependent", v);
-                return DG_ERR_UNSUPPORTED;
-            }
+        for (int v = da; v < db; ++v)     // parallel edges must carry equal weights (always true for graphs built by
+            for (uint32_t e = in_off[v] + 1; e < in_off[v + 1]; ++e)   // Approximator::solve)
+                if ((in_edge[e] & 0x7FFFFFFFu) == (in_edge[e - 1] & 0x7FFFFFFFu) && in_edge[e] != in_edge[e - 1]) {
+                    tfail(t, DG_ERR_UNSUPPORTED, "parallel edges with different weights into vertex %d: tie order would be schedule dependent", v);
+                    return;
+                }
+    });
+    if (int rc = first_error()) return rc;
     lap("validate + in-CSR");
     // colour lists must be sorted (the merges rely on it) and fit the uint16 delta
-    int64_t max_list = 0;
-    for (int v = 0; v < nV; ++v) {
-        for (int pass = 0; pass < 2; ++pass) {
-            const int64_t *off = pass ? g->het_off : g->hom_off;
-            const int32_t *colv = pass ? g->het_col : g->hom_col;
-            if (off[v + 1] < off[v]) { set_error("colour offsets not monotone at %d", v); return DG_ERR_ARG; }
-            max_list = std::max(max_list, off[v + 1] - off[v]);
-            for (int64_t q = off[v] + 1; q < off[v + 1]; ++q)
-                if (colv[q] <= colv[q - 1]) { set_error("colour list of vertex %d is not sorted-unique", v); return DG_ERR_ARG; }
+    if (g->hom_off[0] != 0 || g->het_off[0] != 0) { set_error("colour offsets must start at 0"); return DG_ERR_ARG; }
+    std::vector<int64_t> tmax_list(NT, 0);
+    std::vector<uint8_t> has_col(L, 0);
+    run_threads([&](int t) {
+        const int va = g->level_off[lcut[t]], vb = lcut[t + 1] < L ? g->level_off[lcut[t + 1]] : nV;
+        for (int v = va; v < vb; ++v) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int64_t *off = pass ? g->het_off : g->hom_off;
+                const int32_t *colv = pass ? g->het_col : g->hom_col;
+                if (off[v + 1] < off[v]) { tfail(t, DG_ERR_ARG, "colour offsets not monotone at %d", v); return; }
+                tmax_list[t] = std::max(tmax_list[t], off[v + 1] - off[v]);
+                if (off[v + 1] > off[v]) has_col[level_of[v]] = 1;
+                for (int64_t q = off[v] + 1; q < off[v + 1]; ++q)
+                    if (colv[q] <= colv[q - 1]) { tfail(t, DG_ERR_ARG, "colour list of vertex %d is not sorted-unique", v); return; }
+            }
         }
-    }
+    });
+    if (int rc = first_error()) return rc;
+    int64_t max_list = 0;
+    for (int t = 0; t < NT; ++t) max_list = std::max(max_list, tmax_list[t]);
     if (max_list * 4 > 65535) { set_error("colour lists too long for uint16 score deltas (%lld)", (long long)max_list); return DG_ERR_UNSUPPORTED; }
 
     lap("colour checks");
-    // level descriptors
+    // level descriptors: every thread builds the groups / dead columns / slot blocks of its levels into private
+    // vectors with range-local offsets, a serial prefix over the ranges turns them into global ones
     S.descs.assign(L, LevelDesc{});
-    std::vector<uint8_t> has_col(L, 0);
-    std::vector<int64_t> col_sum(L, 0);   // colour entries per vertex summed per level (for counters)
-    for (int v = 0; v < nV; ++v) {
-        const int64_t n = (g->hom_off[v + 1] - g->hom_off[v]) + (g->het_off[v + 1] - g->het_off[v]);
-        if (n) has_col[level_of[v]] = 1;
-    }
     S.cells = S.relaxations = S.edge_pairs = S.colour_entries = 0;
     S.total_cells = 0; S.max_level_cells = S.RP; S.delta_entries = DELTA_PAD;
-    std::vector<int32_t> dtrans, dead_cols;
-    std::vector<uint32_t> grp_begin;
-    std::vector<uint32_t> slots;                 // 2 words per slot, 64 slots per group
     std::vector<uint32_t> rowrec((size_t)nV * 4, 0);
-    for (int v = 0; v < nV; ++v) {
-        const uint32_t e0 = in_off[v], dv = in_off[v + 1] - e0;
-        rowrec[4 * (size_t)v] = e0; rowrec[4 * (size_t)v + 1] = dv;
-        rowrec[4 * (size_t)v + 2] = dv > 0 ? in_edge[e0] : 0; rowrec[4 * (size_t)v + 3] = dv > 1 ? in_edge[e0 + 1] : 0;
-    }
-    std::vector<int64_t> dblk_first;
-    int64_t nblk = 0;
-    for (int l = 1; l < L; ++l) {
-        LevelDesc &d = S.descs[l];
-        d.a0 = g->level_off[l - 1]; d.k = g->level_off[l] - d.a0;
-        d.b0 = g->level_off[l]; d.k2 = g->level_off[l + 1] - d.b0;
-        d.in_base = in_off[d.b0];
-        d.T = (int32_t)(in_off[d.b0 + d.k2] - d.in_base);
-        // column groups: greedy runs of whole columns with <= 64 in-edges; a column with more gets its own group
-        d.grp_first = (int32_t)grp_begin.size();
-        d.dead_first = (int32_t)dead_cols.size();
-        {
-            uint32_t cur_size = 0;
-            for (int c = 0; c < d.k2; ++c) {
-                const uint32_t e0 = in_off[d.b0 + c], dv = in_off[d.b0 + c + 1] - e0;
-                if (dv == 0) { dead_cols.push_back(c); continue; }
-                if (cur_size == 0 || cur_size + dv > 64 || dv > 64) { grp_begin.push_back(e0); cur_size = 0; }
-                cur_size += dv;
-                if (dv > 64) cur_size = 65;                      // force a new group after a giant column
-            }
+    struct Part {
+        std::vector<int32_t> dtrans, dead_cols;
+        std::vector<uint32_t> grp_begin, slots;
+        std::vector<int64_t> dblk_first;
+        int64_t cells = 0, max_level_cells = 0, delta_entries = 0, nblk = 0;
+        uint64_t edge_pairs = 0, colour_entries = 0;
+    };
+    std::vector<Part> part(NT);
+    run_threads([&](int t) {
+        Part &P = part[t];
+        const int va = g->level_off[lcut[t]], vb = lcut[t + 1] < L ? g->level_off[lcut[t + 1]] : nV;
+        for (int v = va; v < vb; ++v) {
+            const uint32_t e0 = in_off[v], dv = in_off[v + 1] - e0;
+            rowrec[4 * (size_t)v] = e0; rowrec[4 * (size_t)v + 1] = dv;
+            rowrec[4 * (size_t)v + 2] = dv > 0 ? in_edge[e0] : 0; rowrec[4 * (size_t)v + 3] = dv > 1 ? in_edge[e0 + 1] : 0;
         }
-        d.ngroups = (int32_t)grp_begin.size() - d.grp_first;
-        grp_begin.push_back(d.in_base + (uint32_t)d.T);          // sentinel: end of the level's in-edges
-        // 64-wide slot table of the fast kernel: one block per group; a giant column (in-degree > 64) takes
-        // ceil(dv/64) consecutive blocks (first one tagged 15, the rest 14) and counts as that many "groups"
-        d.slot_first = (int64_t)(slots.size() / 2);
-        d.fast_ok = (d.T < (1 << 28)) ? 1 : 0;
-        int32_t n_blocks = 0;
-        for (int gi = 0; gi < d.ngroups; ++gi) {
-            const uint32_t gb0 = grp_begin[d.grp_first + gi], ge0 = grp_begin[d.grp_first + gi + 1];
-            const bool giant = ge0 - gb0 > 64;
-            if (giant && d.fast_ok) d.fast_ok = 2;               // the general sweep variant
-            uint32_t maxdv = 1;
-            if (!giant)
-                for (uint32_t e = gb0; e < ge0;) {
-                    const int cc = in_dst[e] - d.b0;
-                    const uint32_t dv = in_off[d.b0 + cc + 1] - in_off[d.b0 + cc];
-                    maxdv = std::max(maxdv, dv);
-                    e += dv;
+        auto &grp_begin = P.grp_begin; auto &dead_cols = P.dead_cols; auto &slots = P.slots;
+        for (int l = std::max(1, lcut[t]); l < lcut[t + 1]; ++l) {
+            LevelDesc &d = S.descs[l];
+            d.a0 = g->level_off[l - 1]; d.k = g->level_off[l] - d.a0;
+            d.b0 = g->level_off[l]; d.k2 = g->level_off[l + 1] - d.b0;
+            d.in_base = in_off[d.b0];
+            d.T = (int32_t)(in_off[d.b0 + d.k2] - d.in_base);
+            // column groups: greedy runs of whole columns with <= 64 in-edges; a column with more gets its own group
+            d.grp_first = (int32_t)grp_begin.size();
+            d.dead_first = (int32_t)dead_cols.size();
+            {
+                uint32_t cur_size = 0;
+                for (int c = 0; c < d.k2; ++c) {
+                    const uint32_t e0 = in_off[d.b0 + c], dv = in_off[d.b0 + c + 1] - e0;
+                    if (dv == 0) { dead_cols.push_back(c); continue; }
+                    if (cur_size == 0 || cur_size + dv > 64 || dv > 64) { grp_begin.push_back(e0); cur_size = 0; }
+                    cur_size += dv;
+                    if (dv > 64) cur_size = 65;                      // force a new group after a giant column
                 }
-            uint32_t steps = 0;
-            while ((1u << steps) < std::min(maxdv, 64u)) ++steps;
-            const uint32_t nb = giant ? (ge0 - gb0 + 63) / 64 : 1;
-            for (uint32_t bq = 0; bq < nb; ++bq) {
-                const uint32_t tag = giant ? (bq == 0 ? 15u : 14u) : steps;
-                for (uint32_t q = 0; q < 64; ++q) {
-                    const uint32_t e = gb0 + bq * 64 + q;
-                    if (e < ge0) {
-                        const uint32_t pv = in_edge[e];
-                        slots.push_back((pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16));
-                        slots.push_back((e - d.in_base) | (tag << 28));
-                    } else {
-                        slots.push_back(0xFFFFFFFFu);
-                        slots.push_back(tag << 28);
+            }
+            d.ngroups = (int32_t)grp_begin.size() - d.grp_first;
+            grp_begin.push_back(d.in_base + (uint32_t)d.T);          // sentinel: end of the level's in-edges
+            // 64-wide slot table of the fast kernel: one block per group; a giant column (in-degree > 64) takes
+            // ceil(dv/64) consecutive blocks (first one tagged 15, the rest 14) and counts as that many "groups"
+            d.slot_first = (int64_t)(slots.size() / 2);
+            d.fast_ok = (d.T < (1 << 28)) ? 1 : 0;
+            int32_t n_blocks = 0;
+            for (int gi = 0; gi < d.ngroups; ++gi) {
+                const uint32_t gb0 = grp_begin[d.grp_first + gi], ge0 = grp_begin[d.grp_first + gi + 1];
+                const bool giant = ge0 - gb0 > 64;
+                if (giant && d.fast_ok) d.fast_ok = 2;               // the general sweep variant
+                uint32_t maxdv = 1;
+                if (!giant)
+                    for (uint32_t e = gb0; e < ge0;) {
+                        const int cc = in_dst[e] - d.b0;
+                        const uint32_t dv = in_off[d.b0 + cc + 1] - in_off[d.b0 + cc];
+                        maxdv = std::max(maxdv, dv);
+                        e += dv;
+                    }
+                uint32_t steps = 0;
+                while ((1u << steps) < std::min(maxdv, 64u)) ++steps;
+                const uint32_t nb = giant ? (ge0 - gb0 + 63) / 64 : 1;
+                const size_t s0 = slots.size();
+                slots.resize(s0 + (size_t)nb * 128);
+                uint32_t *sp = slots.data() + s0;
+                for (uint32_t bq = 0; bq < nb; ++bq) {
+                    const uint32_t tag = giant ? (bq == 0 ? 15u : 14u) : steps;
+                    for (uint32_t q = 0; q < 64; ++q, sp += 2) {
+                        const uint32_t e = gb0 + bq * 64 + q;
+                        if (e < ge0) {
+                            const uint32_t pv = in_edge[e];
+                            sp[0] = (pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16);
+                            sp[1] = (e - d.in_base) | (tag << 28);
+                        } else {
+                            sp[0] = 0xFFFFFFFFu;
+                            sp[1] = tag << 28;
+                        }
                     }
                 }
+                n_blocks += (int32_t)nb;
             }
-            n_blocks += (int32_t)nb;
-        }
-        if (n_blocks == 0) {                                     // level without in-edges: one all-padding block
-            for (int q = 0; q < 64; ++q) { slots.push_back(0xFFFFFFFFu); slots.push_back(0); }
-            n_blocks = 1;
-        }
-        d.nblocks = n_blocks;
-        d.ndead = (int32_t)dead_cols.size() - d.dead_first;
-        if (d.ngroups == 0) { d.ngroups = 1; grp_begin.push_back(d.in_base + (uint32_t)d.T); }   // level without in-edges: one empty group
-        const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
-        d.bp_off = S.total_cells;
-        S.total_cells += ncell;
-        S.max_level_cells = std::max(S.max_level_cells, ncell);
-        S.cells += (uint64_t)ncell;
-        S.edge_pairs += (uint64_t)d.T * (uint64_t)d.T;
-        if (has_col[l - 1] || has_col[l]) {
-            d.delta_off = S.delta_entries;
-            S.delta_entries += (int64_t)d.T * d.T;
-            dtrans.push_back(l);
-            dblk_first.push_back(nblk);
-            nblk += ((int64_t)d.T * d.T + DELTA_PER_BLOCK - 1) / DELTA_PER_BLOCK;
-            int64_t f = 0;   // sum over in-edges of |col(src)| + |col(dst)|
-            for (uint32_t e = d.in_base; e < d.in_base + (uint32_t)d.T; ++e) {
-                const int s = d.a0 + (int)(in_edge[e] & 0x7FFFFFFFu), t = in_dst[e];
-                f += (g->hom_off[s + 1] - g->hom_off[s]) + (g->het_off[s + 1] - g->het_off[s]) +
-                     (g->hom_off[t + 1] - g->hom_off[t]) + (g->het_off[t + 1] - g->het_off[t]);
+            if (n_blocks == 0) {                                     // level without in-edges: one all-padding block
+                for (int q = 0; q < 64; ++q) { slots.push_back(0xFFFFFFFFu); slots.push_back(0); }
+                n_blocks = 1;
             }
-            S.colour_entries += (uint64_t)(2 * (int64_t)d.T * f);
-        } else {
-            d.delta_off = -1;
+            d.nblocks = n_blocks;
+            d.ndead = (int32_t)dead_cols.size() - d.dead_first;
+            if (d.ngroups == 0) { d.ngroups = 1; grp_begin.push_back(d.in_base + (uint32_t)d.T); }   // level without in-edges: one empty group
+            const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
+            d.bp_off = P.cells;                                      // range-local for now
+            P.cells += ncell;
+            P.max_level_cells = std::max(P.max_level_cells, ncell);
+            P.edge_pairs += (uint64_t)d.T * (uint64_t)d.T;
+            if (has_col[l - 1] || has_col[l]) {
+                d.delta_off = P.delta_entries;                       // range-local for now
+                P.delta_entries += (int64_t)d.T * d.T;
+                P.dtrans.push_back(l);
+                P.dblk_first.push_back(P.nblk);
+                P.nblk += ((int64_t)d.T * d.T + DELTA_PER_BLOCK - 1) / DELTA_PER_BLOCK;
+                int64_t f = 0;   // sum over in-edges of |col(src)| + |col(dst)|
+                for (uint32_t e = d.in_base; e < d.in_base + (uint32_t)d.T; ++e) {
+                    const int sv = d.a0 + (int)(in_edge[e] & 0x7FFFFFFFu), tv = in_dst[e];
+                    f += (g->hom_off[sv + 1] - g->hom_off[sv]) + (g->het_off[sv + 1] - g->het_off[sv]) +
+                         (g->hom_off[tv + 1] - g->hom_off[tv]) + (g->het_off[tv + 1] - g->het_off[tv]);
+                }
+                P.colour_entries += (uint64_t)(2 * (int64_t)d.T * f);
+            } else {
+                d.delta_off = -1;
+            }
         }
+    });
+    // serial prefix over the ranges, then every range shifts its levels and copies its vectors into place
+    std::vector<int64_t> b_grp(NT + 1, 0), b_dead(NT + 1, 0), b_slot(NT + 1, 0), b_cells(NT + 1, 0), b_delta(NT + 1, DELTA_PAD), b_blk(NT + 1, 0), b_dt(NT + 1, 0);
+    for (int t = 0; t < NT; ++t) {
+        const Part &P = part[t];
+        b_grp[t + 1] = b_grp[t] + (int64_t)P.grp_begin.size();
+        b_dead[t + 1] = b_dead[t] + (int64_t)P.dead_cols.size();
+        b_slot[t + 1] = b_slot[t] + (int64_t)P.slots.size() / 2;
+        b_cells[t + 1] = b_cells[t] + P.cells;
+        b_delta[t + 1] = b_delta[t] + P.delta_entries;
+        b_blk[t + 1] = b_blk[t] + P.nblk;
+        b_dt[t + 1] = b_dt[t] + (int64_t)P.dtrans.size();
+        S.max_level_cells = std::max(S.max_level_cells, P.max_level_cells);
+        S.edge_pairs += P.edge_pairs;
+        S.colour_entries += P.colour_entries;
     }
+    S.total_cells = b_cells[NT];
+    S.cells = (uint64_t)b_cells[NT];
+    S.delta_entries = b_delta[NT];
+    const int64_t nblk = b_blk[NT];
+    if (b_grp[NT] >= (int64_t)1 << 31 || b_dead[NT] >= (int64_t)1 << 31) { set_error("group tables too large"); return DG_ERR_UNSUPPORTED; }
+    std::vector<int32_t> dtrans((size_t)b_dt[NT]), dead_cols((size_t)b_dead[NT]);
+    std::vector<uint32_t> grp_begin((size_t)b_grp[NT]);
+    std::vector<uint32_t> slots((size_t)b_slot[NT] * 2);         // 2 words per slot, 64 slots per block
+    std::vector<int64_t> dblk_first((size_t)b_dt[NT]);
+    run_threads([&](int t) {
+        Part &P = part[t];
+        for (int l = std::max(1, lcut[t]); l < lcut[t + 1]; ++l) {
+            LevelDesc &d = S.descs[l];
+            d.grp_first += (int32_t)b_grp[t];
+            d.dead_first += (int32_t)b_dead[t];
+            d.slot_first += b_slot[t];
+            d.bp_off += b_cells[t];
+            if (d.delta_off >= 0) d.delta_off += b_delta[t];
+        }
+        std::copy(P.grp_begin.begin(), P.grp_begin.end(), grp_begin.begin() + b_grp[t]);
+        std::copy(P.dead_cols.begin(), P.dead_cols.end(), dead_cols.begin() + b_dead[t]);
+        std::copy(P.slots.begin(), P.slots.end(), slots.begin() + 2 * b_slot[t]);
+        std::copy(P.dtrans.begin(), P.dtrans.end(), dtrans.begin() + b_dt[t]);
+        for (size_t q = 0; q < P.dblk_first.size(); ++q) dblk_first[(size_t)b_dt[t] + q] = P.dblk_first[q] + b_blk[t];
+        Part().dtrans.swap(P.dtrans); std::vector<uint32_t>().swap(P.slots);
+    });
     S.relaxations = S.edge_pairs * (uint64_t)S.RP;
     S.n_delta_blocks = nblk;
     if (nblk >= (int64_t)1 << 31) { set_error("delta grid too large"); return DG_ERR_UNSUPPORTED; }
@@ -1513,6 +1614,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "host_threads")) c->dp->host_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (default 2^31 cells = 8 GB)
         if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
         dgi::pool_clear(*c->dp);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <tuple>
 #include <unordered_map>
@@ -211,6 +212,10 @@ bool read_gfa_file(const std::string &path, GfaGraph &g, std::string &err) {
     gzFile fp = path == "-" ? gzdopen(0, "r") : gzopen(path.c_str(), "r");
     if (!fp) { err = "cannot open " + path; return false; }
     gzbuffer(fp, 1 << 20);
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    double tl = now();
+    auto lap = [&](const char *w) { if (dbg) { double t = now(); fprintf(stderr, "[dg::gfa] %-18s %.3f s\n", w, t - tl); tl = t; } };
     Builder b(g);
     LineReader lr(fp);
     std::string line;
@@ -225,8 +230,11 @@ bool read_gfa_file(const std::string &path, GfaGraph &g, std::string &err) {
         else parse_W(b, f);
     }
     gzclose(fp);
+    lap("read + parse lines");
     walk_flip(g);
+    lap("walk_flip");
     finalize(b);
+    lap("finalize arcs");
     return true;
 }
 

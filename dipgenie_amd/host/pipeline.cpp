@@ -72,7 +72,35 @@ void Pipeline::read_gfa_from(const GfaGraph &g) {
         int64_t fallback_start = (max_seed >= 0 ? max_seed + 1 : 0);
         for (int32_t v = 0; v < V; ++v) if (pos[v] == INF) pos[v] = fallback_start;
     }
-    bool changed = true;                                               // :158-171
+    // :158-171 relaxes pos[v] >= pos[u] + 1 over consecutive path steps until nothing changes.  That loop converges
+    // to the least fixed point above the seeds, which on an acyclic step graph is what one longest-path pass in
+    // topological order gives (dozens of whole-panel passes at 24 walks otherwise); a cyclic step graph keeps the
+    // literal loop, iteration cap included.
+    bool relaxed = false;
+    {
+        std::vector<int64_t> eoff((size_t)V + 1, 0);
+        for (const auto &pw : paths) for (size_t t = 1; t < pw.size(); ++t) eoff[pw[t - 1] + 1]++;
+        for (int32_t v = 0; v < V; ++v) eoff[v + 1] += eoff[v];
+        std::vector<int32_t> edst((size_t)eoff[V]), indeg(V, 0);
+        {
+            std::vector<int64_t> fill(eoff.begin(), eoff.end() - 1);
+            for (const auto &pw : paths) for (size_t t = 1; t < pw.size(); ++t) { edst[fill[pw[t - 1]]++] = (int32_t)pw[t]; indeg[pw[t]]++; }
+        }
+        std::vector<int32_t> queue;
+        queue.reserve(V);
+        for (int32_t v = 0; v < V; ++v) if (indeg[v] == 0) queue.push_back(v);
+        std::vector<int64_t> lp(pos);
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+            const int32_t u = queue[qi];
+            for (int64_t e = eoff[u]; e < eoff[u + 1]; ++e) {
+                const int32_t v = edst[e];
+                if (lp[v] < lp[u] + 1) lp[v] = lp[u] + 1;
+                if (--indeg[v] == 0) queue.push_back(v);
+            }
+        }
+        if ((int32_t)queue.size() == V) { pos.swap(lp); relaxed = true; }
+    }
+    bool changed = !relaxed;
     int iter = 0, iter_cap = std::max(10, V);
     while (changed && iter++ < iter_cap) {
         changed = false;
@@ -114,7 +142,9 @@ int Pipeline::load_graph(std::string &err) {
     double t0 = now_s();
     GfaGraph g;
     if (!read_gfa_file(opt.gfa_file, g, err)) return -1;
+    const double t1 = now_s();
     read_gfa_from(g);
+    if (getenv("DG_DEBUG")) fprintf(stderr, "[dg::gfa] file %.3f s, read_gfa (adjacency, paths, column order) %.3f s\n", t1 - t0, now_s() - t1);
     stamp("gfa_read+read_gfa", t0);
     return 0;
 }
@@ -137,10 +167,18 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     struct HapIndex { std::vector<uint64_t> hash; std::vector<uint32_t> voff; std::vector<int32_t> v; };
     std::vector<HapIndex> kmer_index(num_walks);
     sum.minimizers_per_hap.assign(num_walks, 0);
-    for (uint32_t h = 0; h < num_walks; ++h) {
+    double t_sketch = 0;
+    int rc_sketch = 0;
+    std::string err_sketch;
+    // The backend calls are issued by one thread, back to back (a ctx is not thread-safe); the position -> vertex-span
+    // mapping of a finished haplotype (:343-357) runs as a task on the other threads meanwhile.
+#pragma omp parallel num_threads(opt.threads)
+#pragma omp single
+    for (uint32_t h = 0; h < num_walks && rc_sketch == 0; ++h) {
         std::string hap;                                               // :283-285
-        std::vector<int64_t> seg_start(paths[h].size() + 1, 0);
+        auto *seg_start_p = new std::vector<int64_t>(paths[h].size() + 1, 0);
         {
+            std::vector<int64_t> &seg_start = *seg_start_p;
             size_t tot = 0;
             for (size_t i = 0; i < paths[h].size(); ++i) { seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
             seg_start[paths[h].size()] = (int64_t)tot;
@@ -148,39 +186,53 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             for (size_t i = 0; i < paths[h].size(); ++i) hap += node_seq[paths[h][i]];
         }
         uint64_t *hh = nullptr; int64_t *pp = nullptr; int64_t n = 0;
+        const double ts0 = now_s();
         int rc = be.sketch_haplotype(be.ctx, hap.data(), (int64_t)hap.size(), k, opt.w, &hh, &pp, &n);
-        if (rc != 0) { err = std::string("sketch_haplotype failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
-        HapIndex &ix = kmer_index[h];
-        ix.hash.assign(hh, hh + n);
-        ix.voff.reserve(n + 1);
-        ix.voff.push_back(0);
-        std::vector<int32_t> uniq;
-        size_t seg = 0;
-        for (int64_t m = 0; m < n; ++m) {                              // :343-357 position -> vertex span
-            int64_t p = pp[m];
-            // positions are non-decreasing; seg = index of the path step containing base p
-            if (seg_start[seg] > p) seg = 0;
-            while (seg + 1 < seg_start.size() - 1 && seg_start[seg + 1] <= p) ++seg;
-            uniq.clear();
-            size_t s2 = seg;
-            for (;;) {
-                int32_t vtx = (int32_t)paths[h][s2];
-                if (seg_start[s2 + 1] > seg_start[s2] &&               // empty segments contribute no base
-                    std::find(uniq.begin(), uniq.end(), vtx) == uniq.end()) uniq.push_back(vtx);
-                if (seg_start[s2 + 1] >= p + k) break;
-                ++s2;
-            }
-            std::sort(uniq.begin(), uniq.end(), [&](int32_t a, int32_t b) { return top_order_map[a] < top_order_map[b]; });
-            ix.v.insert(ix.v.end(), uniq.begin(), uniq.end());
-            ix.voff.push_back((uint32_t)ix.v.size());
+        t_sketch += now_s() - ts0;
+        if (rc != 0) {
+            rc_sketch = rc;
+            err_sketch = std::string("sketch_haplotype failed: ") + (be.last_error ? be.last_error() : "?");
+            delete seg_start_p;
+            break;
         }
-        be.free_buf(hh); be.free_buf(pp);
         sum.minimizers_per_hap[h] = n;
+#pragma omp task firstprivate(h, hh, pp, n, seg_start_p)
+        {
+            const std::vector<int64_t> &seg_start = *seg_start_p;
+            HapIndex &ix = kmer_index[h];
+            ix.hash.assign(hh, hh + n);
+            ix.voff.reserve(n + 1);
+            ix.voff.push_back(0);
+            std::vector<int32_t> uniq;
+            size_t seg = 0;
+            for (int64_t m = 0; m < n; ++m) {                          // :343-357 position -> vertex span
+                int64_t p = pp[m];
+                // positions are non-decreasing; seg = index of the path step containing base p
+                if (seg_start[seg] > p) seg = 0;
+                while (seg + 1 < seg_start.size() - 1 && seg_start[seg + 1] <= p) ++seg;
+                uniq.clear();
+                size_t s2 = seg;
+                for (;;) {
+                    int32_t vtx = (int32_t)paths[h][s2];
+                    if (seg_start[s2 + 1] > seg_start[s2] &&           // empty segments contribute no base
+                        std::find(uniq.begin(), uniq.end(), vtx) == uniq.end()) uniq.push_back(vtx);
+                    if (seg_start[s2 + 1] >= p + k) break;
+                    ++s2;
+                }
+                std::sort(uniq.begin(), uniq.end(), [&](int32_t a, int32_t b) { return top_order_map[a] < top_order_map[b]; });
+                ix.v.insert(ix.v.end(), uniq.begin(), uniq.end());
+                ix.voff.push_back((uint32_t)ix.v.size());
+            }
+            be.free_buf(hh); be.free_buf(pp);
+            delete seg_start_p;
+        }
     }
+    if (rc_sketch != 0) { err = err_sketch; return -1; }
     if (!opt.quiet) {
         std::cerr << "Number of Minimizers" << std::endl;              // :467-474
         for (uint32_t h = 0; h < num_walks; ++h) fprintf(stderr, "%s : %d\n", hap_id2name[h].c_str(), (int)sum.minimizers_per_hap[h]);
     }
+    if (getenv("DG_DEBUG")) fprintf(stderr, "[dg::index] backend sketch calls %.3f s of %.3f s\n", t_sketch, now_s() - t0);
     stamp("index_kmers", t0);
 
     // ---- read sketches: Read_hashes / Sp_R / kmer_count (solver.cpp:526-555, 711-732) ----
@@ -215,6 +267,9 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
         const double kk = 5.0 * (double)num_walks;
         be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, 2.5 * (double)max_path * kk * kk * (opt.R + 1)));
     }
+    const bool dbg_a = getenv("DG_DEBUG") != nullptr;
+    double tla = now_s();
+    auto lap_a = [&](const char *w) { if (dbg_a) { double t = now_s(); fprintf(stderr, "[dg::anchors] %-18s %.3f s\n", w, t - tla); tla = t; } };
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
     std::vector<std::vector<int32_t>> ids(num_walks);
@@ -227,6 +282,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             ids[h][m] = (it != sp_hash.end() && *it == ix.hash[m]) ? (int32_t)(it - sp_hash.begin()) : -1;
         }
     }
+    lap_a("dictionary lookup");
     for (uint32_t h = 0; h < num_walks; ++h)
         for (int32_t id : ids[h]) if (id >= 0) bucket_off[id + 1]++;
     for (int32_t r = 0; r < count_sp_r; ++r) bucket_off[r + 1] += bucket_off[r];
@@ -238,6 +294,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
                 if (ids[h][m] >= 0) raw[fill[ids[h][m]]++] = Raw{(int32_t)h, (uint32_t)m};
     }
 
+    lap_a("bucket by id");
     // ---- shared-anchor filter (:590-633) + occurrence sort (:641-663) ----
     occs.clear(); vpool.clear();
     const float thr = opt.threshold * num_walks;                       // float * uint32 -> float (:618)
@@ -304,6 +361,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             }
         }
     }
+    lap_a("filter + sort");
     {
         size_t no = 0, nv = 0;
         for (int c = 0; c < n_chunks; ++c) { no += occs_c[c].size(); nv += vpool_c[c].size(); }
@@ -314,6 +372,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             for (Occ o : occs_c[c]) { o.off += base; occs.push_back(o); }
         }
     }
+    lap_a("concatenate");
     sum.anchors_per_hap.assign(num_walks, 0);
     for (auto &o : occs) sum.anchors_per_hap[o.h]++;
     if (!opt.quiet) {

@@ -16,6 +16,6 @@ for rep in range(reps):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     print(f"run {rep}: rc={p.returncode} wall {time.time()-t0:.2f}s", flush=True)
     for line in p.stderr.decode().split("\n"):
-        if any(k in line for k in ("stage]", "lattice", "dg::dp", "dipgenie_hip]", "Real time", "[E::")): print("  ", line)
+        if any(k in line for k in ("stage]", "lattice", "dg::", "dipgenie_hip]", "Real time", "[E::")): print("  ", line)
     if p.returncode == 0:
         print("  md5", hashlib.md5(open(f"{d}/o{rep}.fa", "rb").read()).hexdigest(), {k: v for k, v in json.load(open(f"{d}/o.json")).items() if k != "stages"}, flush=True)
