@@ -27,8 +27,13 @@
 namespace dgi {
 
 constexpr int32_t NEG_INF = INT32_MIN / 4;              // approximator.cpp:413
-constexpr uint32_t BP_NONE = 0xFFFFFFFFu;
-constexpr int MAX_K = 1 << 15;                          // back-pointer packs positions in 15 bits
+constexpr uint32_t BP_NONE = 0xFFFFFFFFu;              // wide (32-bit) back-pointer of an unreachable cell
+constexpr int MAX_K = 1 << 15;                          // hop words pack positions in 15 bits
+// Back-pointers are 16 bits per cell: (eu << 8) | ev, the ranks of the winning in-edges inside the destination row's
+// and column's in-edge lists (sorted by source position, so rank order IS the reference's (pred_i asc, pred_j asc)
+// tie order); 0xFFFF = unreachable.  Only a level with an in-degree > 255 keeps the wide word
+// pred_i | pred_j << 15 | wu << 30 | wv << 31 (two 16-bit units per cell) and runs on the generic kernel.
+constexpr int BP_MAX_RANK = 255;
 
 struct LevelDesc {                                      // transition (l-1) -> l, indexed by l
     int32_t a0, k;                                      // source level: first vertex id, width
@@ -36,11 +41,12 @@ struct LevelDesc {                                      // transition (l-1) -> l
     uint32_t in_base;                                   // first in-edge of the destination level
     int32_t T;                                          // in-edges into the destination level
     int64_t delta_off;                                  // offset of the T*T uint16 matrix, -1 if all zero
-    int64_t bp_off;                                     // offset of this level's cells in the bp lattice
+    int64_t bp_off;                                     // offset of this level in the bp lattice, in 16-bit units (even)
     int32_t grp_first, ngroups;                         // column groups (runs of <=64 in-edges covering whole columns)
     int32_t dead_first, ndead;                          // destination columns with no in-edge
     int64_t slot_first;                                 // first entry of this level in the 64-wide slot table
     int32_t fast_ok, nblocks;                           // fast kernel usable; number of 64-slot blocks (>= ngroups: giant columns take several)
+    int32_t bp_wide, bp_nt;                             // wide back-pointers on this level; stream them with non-temporal stores
 };
 
 struct TraceOut {
@@ -60,13 +66,17 @@ struct DpState {
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     int64_t segment_cells = 0;                          // option: force segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // option: threads used by dg_dp_load_graph's table construction
+    int64_t bp_nt_min_cells = 16384;                    // option: levels with at least this many cells stream their back-pointers non-temporally
+    int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
     std::vector<Segment> schedule;
     size_t state_alloc_bytes = 0;
     std::vector<LevelDesc> descs;
     uint64_t cells = 0, relaxations = 0, edge_pairs = 0, colour_entries = 0;
-    int64_t total_cells = 0, max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
+    int64_t total_units = 0, max_level_units = 0;       // back-pointer lattice, in 16-bit units (1 per cell, 2 on wide levels)
+    int64_t max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
+    std::vector<int64_t> level_units;                   // units of every level (even)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
     DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
     std::vector<uint64_t> digest_host;
@@ -79,8 +89,8 @@ struct DpState {
     struct Pool {
         std::mutex mu;
         std::condition_variable cv;
-        std::vector<void *> chunks;           // each chunk_cells * 4 bytes
-        size_t chunk_cells = (size_t)2 << 30;  // 8 GB
+        std::vector<void *> chunks;           // each chunk_units * 2 bytes
+        size_t chunk_units = (size_t)4 << 30;  // 8 GB
         size_t target = 0;                     // chunks wanted
         size_t cap_chunks = 0;                 // upper bound for reservations made before the graph is known
         bool running = false, failed = false, paused = false;
@@ -196,7 +206,7 @@ struct SweepArgs {
     const int32_t *in_dst, *dead_cols;
     const uint16_t *delta;
     int32_t *buf0, *buf1;
-    uint32_t *bp;
+    uint16_t *bp;
     unsigned long long *digest;
     int RP;
 };
@@ -208,6 +218,12 @@ __device__ __forceinline__ uint32_t bp_from_ord(uint32_t o) {
     const uint32_t i = 0x7FFFu - (o >> 17), j = 0x7FFFu - ((o >> 2) & 0x7FFFu);
     return i | (j << 15) | (((o >> 1) & 1u) << 30) | ((o & 1u) << 31);
 }
+// narrow form: ord = (255 - eu) << 8 | (255 - ev) is never 0 for a real candidate, and the stored back-pointer is
+// simply ~ord (an untouched best keeps ord 0 -> 0xFFFF = unreachable)
+// non-temporal 16-bit store as inline asm: with the builtin on one side of a branch and a plain store on the other the
+// optimiser merges the two into ONE plain store (the !nontemporal hint is dropped)
+__device__ __forceinline__ void store_bp_nt(uint16_t *p, uint32_t v) { asm volatile("global_store_short %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t ord_rank(int eu, int ev) { return ((uint32_t)(BP_MAX_RANK - eu) << 8) | (uint32_t)(BP_MAX_RANK - ev); }
 
 template <int RC, bool DIGEST>
 __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, int wave_id, int n_waves) {
@@ -239,11 +255,13 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
         for (uint32_t cb = gbeg; cb < gend; cb += 64) {
             const uint32_t ev = cb + lane;
             const bool act = ev < gend;
-            int j = 0, wv = 0;
+            int j = 0, wv = 0, evr = 0;
             if (act) {
                 const uint32_t pv = A.in_edge[ev];
                 j = (int)(pv & 0x7FFFFFFFu); wv = (int)(pv >> 31);
-                j2 = A.in_dst[ev] - d.b0;
+                const int cv = A.in_dst[ev];
+                j2 = cv - d.b0;
+                if (!d.bp_wide) evr = (int)(ev - A.in_off[cv]);            // rank inside the column's in-edge list
             }
             const int dcol = (int)(ev - d.in_base) & dmask;
             for (uint32_t eu = eu0; eu < eu1; ++eu) {
@@ -252,7 +270,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (act) {
                     const int w = wu + wv;
                     const int dl = (int)dm[(int64_t)(eu - d.in_base) * dT + dcol];
-                    const uint32_t ord = ord_word(i, j, wu, wv);
+                    const uint32_t ord = d.bp_wide ? ord_word(i, j, wu, wv) : ord_rank((int)(eu - eu0), evr);
                     // rows r = r2 - w; the buffers carry front/tail padding so r = -1, -2 (and r2 >= RP in a
                     // ragged last chunk) are legal reads that the select discards: RC loads back to back
                     const int32_t *base = cur + ((int64_t)i * RP + (r0 - w)) * d.k + j;
@@ -293,7 +311,10 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r2 < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                     nxt[idx] = bval[q];
-                    if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
+                    if (A.bp) {
+                        if (d.bp_wide) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), (uint32_t *)(A.bp + d.bp_off + 2 * idx));
+                        else __builtin_nontemporal_store((uint16_t)~bord[q], &A.bp[d.bp_off + idx]);
+                    }
                     if (DIGEST && bval[q] != NEG_INF) {
                         const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                         dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -308,7 +329,10 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
                 if (r0 + q < RP) {
                     const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                     nxt[idx] = NEG_INF;
-                    if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
+                    if (A.bp) {
+                        if (d.bp_wide) __builtin_nontemporal_store((uint32_t)(BP_NONE), (uint32_t *)(A.bp + d.bp_off + 2 * idx));
+                        else __builtin_nontemporal_store((uint16_t)0xFFFFu, &A.bp[d.bp_off + idx]);
+                    }
                 }
             }
         }
@@ -337,7 +361,7 @@ struct FastArgs {
     const int32_t *dead_cols;
     const uint16_t *delta;
     int32_t *base0, *base1;                             // padded allocation starts of the two state buffers
-    uint32_t *bp;
+    uint16_t *bp;                                       // fast-form levels always store narrow back-pointers
     unsigned long long *digest;
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
     uint32_t buf_bytes;                                 // size of one padded state buffer
@@ -378,7 +402,8 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const bool has_delta = d.delta_off >= 0;
     const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
     const int dT = has_delta ? d.T : 0;
-    const int dcol = has_delta ? (int)(sl.y & 0x0FFFFFFFu) : 0;
+    const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
+    const int evr = (int)((sl.y >> 20) & 0xFFu);                       // rank of this lane's in-edge inside its column's list
     const int du = (int)rr.y;
     uint32_t mypu = 0;
     if (du > 2 && lane < du) mypu = A.in_edge[rr.x + lane];            // du <= 64 on this path
@@ -409,8 +434,8 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
 #pragma unroll
                 for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, AUX);
             }
-            relax_select<RC>(va, dla, ord_word(ia, j, (int)(rr.z >> 31), wv), r0, wa, RP, bval, bord);
-            if (du == 2) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(rr.w >> 31), wv), r0, wb, RP, bval, bord);
+            relax_select<RC>(va, dla, ord_rank(0, evr), r0, wa, RP, bval, bord);
+            if (du == 2) relax_select<RC>(vb, dlb, ord_rank(1, evr), r0, wb, RP, bval, bord);
         }
     } else {
         // heavy rows (recombination fan-in): U in-edges per step -- all their loads (U deltas + U*RC values) go out
@@ -436,8 +461,8 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (t + u < du) {
-                        const int iu = (int)(pu[u] & 0x7FFFFFFFu), wu = (int)(pu[u] >> 31);
-                        relax_select<RC>(vals[u], dl[u], ord_word(iu, j, wu, wv), r0, wu + wv, RP, bval, bord);
+                        const int wu = (int)(pu[u] >> 31);
+                        relax_select<RC>(vals[u], dl[u], ord_rank(t + u, evr), r0, wu + wv, RP, bval, bord);
                     }
                 }
             }
@@ -468,7 +493,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r2 < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                 nxt[idx] = bval[q];
-                if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
                 if (DIGEST && bval[q] != NEG_INF) {
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -482,7 +507,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                 nxt[idx] = NEG_INF;
-                if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], 0xFFFFu); else A.bp[d.bp_off + idx] = (uint16_t)0xFFFFu; }
             }
         }
     }
@@ -531,7 +556,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
         const bool actb = sl.x != 0xFFFFFFFFu;
         act |= actb;
         const int j = (int)(sl.x & 0x7FFFu), wv = (int)((sl.x >> 15) & 1u);
-        const int dcol = has_delta ? (int)(sl.y & 0x0FFFFFFFu) : 0;
+        const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
+        const int evr = (int)((sl.y >> 20) & 0xFFu);
         if (du <= 2) {
             // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
             if (actb && du > 0) {
@@ -549,8 +575,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
 #pragma unroll
                     for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, AUX);
                 }
-                relax_select<RC>(va, dla, ord_word(ia, j, (int)(rr.z >> 31), wv), r0, wa, RP, bval, bord);
-                if (du == 2) relax_select<RC>(vb, dlb, ord_word(ib, j, (int)(rr.w >> 31), wv), r0, wb, RP, bval, bord);
+                relax_select<RC>(va, dla, ord_rank(0, evr), r0, wa, RP, bval, bord);
+                if (du == 2) relax_select<RC>(vb, dlb, ord_rank(1, evr), r0, wb, RP, bval, bord);
             }
         } else {
             // heavy rows (recombination fan-in): the in-edge list is fetched 64 at a time, one per lane, and broadcast
@@ -581,8 +607,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             if (t + u < dc) {
-                                const int iu = (int)(pu[u] & 0x7FFFFFFFu), wu = (int)(pu[u] >> 31);
-                                relax_select<RC>(vals[u], dl[u], ord_word(iu, j, wu, wv), r0, wu + wv, RP, bval, bord);
+                                const int wu = (int)(pu[u] >> 31);
+                                relax_select<RC>(vals[u], dl[u], ord_rank(c0 + t + u, evr), r0, wu + wv, RP, bval, bord);
                             }
                         }
                     }
@@ -615,7 +641,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             if (r2 < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
                 nxt[idx] = bval[q];
-                if (A.bp) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), &A.bp[d.bp_off + idx]);
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
                 if (DIGEST && bval[q] != NEG_INF) {
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     dsum += (unsigned long long)(uint32_t)(bval[q] + 1) * (o + 1);
@@ -629,7 +655,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
                 nxt[idx] = NEG_INF;
-                if (A.bp) __builtin_nontemporal_store((uint32_t)(BP_NONE), &A.bp[d.bp_off + idx]);
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], 0xFFFFu); else A.bp[d.bp_off + idx] = (uint16_t)0xFFFFu; }
             }
         }
     }
@@ -783,9 +809,17 @@ __global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, ever
 // ---------------------------------------------------------------------------------------------
 struct ChainState { int32_t i, j, r, value; };
 
+// Pulls the row records of a range of levels into the memory-side Infinity Cache right before the chain walk reads two
+// of them per level (they were last touched by the sweep, hundreds of GB of lattice writes ago).
+__global__ __launch_bounds__(256) void dp_warm_kernel(const uint4 *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint4 v = p[i]; asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+}
+
 __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
-                                                            const uint32_t *__restrict__ bp /* biased by the segment's first cell */,
+                                                            const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
                                                             const int32_t *__restrict__ final_val /* non-null on the first call */,
+                                                            const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
                                                             uint32_t *__restrict__ path, ChainState *st) {
     const int lane = threadIdx.x & 63;
     int i, j, r, value;
@@ -795,18 +829,38 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
         for (int base = l_hi; base >= l_lo; base -= 64) {
             const int my_l = base - lane;
             long long bo = 0;
-            int kk = 1;
-            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; }
+            int kk = 1, bb = 0;                                         // bb = first vertex of the level | wide << 31
+            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; bb = descs[my_l].b0 | (descs[my_l].bp_wide << 31); }
             const int n = min(64, base - l_lo + 1);
             for (int t = 0; t < n; ++t) {
                 const int l = base - t;
                 const long long bo_l = ((long long)__builtin_amdgcn_readlane((int)(bo >> 32), t) << 32) |
                                        (unsigned int)__builtin_amdgcn_readlane((int)bo, t);
                 const int k2 = __builtin_amdgcn_readlane(kk, t);
-                const uint32_t b = bp[bo_l + ((long long)i * RP + r) * k2 + j];
-                if (lane == 0) path[l] = b;
-                i = (int)(b & 0x7FFFu); j = (int)((b >> 15) & 0x7FFFu);
-                r -= (int)((b >> 30) & 1u) + (int)(b >> 31);
+                const int bw = __builtin_amdgcn_readlane(bb, t);
+                const long long cell = ((long long)i * RP + r) * k2 + j;
+                uint32_t hop;
+                if (bw < 0) {                                           // wide level: the hop word itself
+                    hop = *(const uint32_t *)(bp + bo_l + 2 * cell);
+                } else {
+                    // One round trip: the back-pointer and the two row records go out together (even lanes fetch the
+                    // row's record, odd lanes the column's -- lane-varying addresses, so the compiler can neither turn
+                    // them into scalar loads nor defer them behind the back-pointer); ranks 0 and 1 (97 % of the
+                    // vertices) are inside the record, higher ranks cost one more load.
+                    const int odd = lane & 1;
+                    const uint4 rr = rowrec[bw + (odd ? j : i)];
+                    const uint32_t b = bp[bo_l + cell];
+                    uint32_t e0 = rr.x;
+                    asm volatile("" : "+v"(e0));                        // keep the whole record in the first round trip
+                    const uint32_t rank = odd ? (b & 0xFFu) : (b >> 8);
+                    uint32_t p = rank == 0 ? rr.z : rr.w;
+                    if (rank > 1) p = in_edge[e0 + rank];
+                    const uint32_t pu = (uint32_t)__builtin_amdgcn_readlane((int)p, 0), pv = (uint32_t)__builtin_amdgcn_readlane((int)p, 1);
+                    hop = (pu & 0x7FFFu) | ((pv & 0x7FFFu) << 15) | ((pu >> 31) << 30) | ((pv >> 31) << 31);
+                }
+                if (lane == 0) path[l] = hop;
+                i = (int)(hop & 0x7FFFu); j = (int)((hop >> 15) & 0x7FFFu);
+                r -= (int)((hop >> 30) & 1u) + (int)(hop >> 31);
             }
         }
     }
@@ -878,7 +932,7 @@ static void pool_request(DpState &S, int device, size_t target) {
                 std::unique_lock<std::mutex> lk2(Sp->pool.mu);
                 Sp->pool.cv.wait(lk2, [&] { return !Sp->pool.paused; });
                 if (Sp->pool.chunks.size() >= Sp->pool.target) { Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
-                bytes = Sp->pool.chunk_cells * 4;
+                bytes = Sp->pool.chunk_units * 2;
             }
             void *q = nullptr;
             const hipError_t e = hipMalloc(&q, bytes);
@@ -1051,13 +1105,14 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     // vectors with range-local offsets, a serial prefix over the ranges turns them into global ones
     S.descs.assign(L, LevelDesc{});
     S.cells = S.relaxations = S.edge_pairs = S.colour_entries = 0;
-    S.total_cells = 0; S.max_level_cells = S.RP; S.delta_entries = DELTA_PAD;
+    S.total_units = 0; S.max_level_units = 0; S.max_level_cells = S.RP; S.delta_entries = DELTA_PAD;
+    S.level_units.assign(L, 0);
     std::vector<uint32_t> rowrec((size_t)nV * 4, 0);
     struct Part {
         std::vector<int32_t> dtrans, dead_cols;
         std::vector<uint32_t> grp_begin, slots;
         std::vector<int64_t> dblk_first;
-        int64_t cells = 0, max_level_cells = 0, delta_entries = 0, nblk = 0;
+        int64_t cells = 0, units = 0, max_level_cells = 0, max_level_units = 0, delta_entries = 0, nblk = 0;
         uint64_t edge_pairs = 0, colour_entries = 0;
     };
     std::vector<Part> part(NT);
@@ -1094,7 +1149,11 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             // 64-wide slot table of the fast kernel: one block per group; a giant column (in-degree > 64) takes
             // ceil(dv/64) consecutive blocks (first one tagged 15, the rest 14) and counts as that many "groups"
             d.slot_first = (int64_t)(slots.size() / 2);
-            d.fast_ok = (d.T < (1 << 28)) ? 1 : 0;
+            d.fast_ok = (d.T < (1 << 20)) ? 1 : 0;                   // the slot word keeps 20 bits of in-edge index
+            uint32_t max_indeg = 0;
+            for (int c = 0; c < d.k2; ++c) max_indeg = std::max(max_indeg, in_off[d.b0 + c + 1] - in_off[d.b0 + c]);
+            d.bp_wide = max_indeg > (uint32_t)BP_MAX_RANK ? 1 : 0;  // ranks do not fit 8 bits: wide words, generic kernel
+            if (d.bp_wide) d.fast_ok = 0;
             int32_t n_blocks = 0;
             for (int gi = 0; gi < d.ngroups; ++gi) {
                 const uint32_t gb0 = grp_begin[d.grp_first + gi], ge0 = grp_begin[d.grp_first + gi + 1];
@@ -1121,7 +1180,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
                         if (e < ge0) {
                             const uint32_t pv = in_edge[e];
                             sp[0] = (pv & 0x7FFFu) | ((pv >> 31) << 15) | ((uint32_t)(in_dst[e] - d.b0) << 16);
-                            sp[1] = (e - d.in_base) | (tag << 28);
+                            sp[1] = (e - d.in_base) | ((e - in_off[in_dst[e]]) << 20) | (tag << 28);   // in-edge, its rank in the column, tag
                         } else {
                             sp[0] = 0xFFFFFFFFu;
                             sp[1] = tag << 28;
@@ -1138,9 +1197,13 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             d.ndead = (int32_t)dead_cols.size() - d.dead_first;
             if (d.ngroups == 0) { d.ngroups = 1; grp_begin.push_back(d.in_base + (uint32_t)d.T); }   // level without in-edges: one empty group
             const int64_t ncell = (int64_t)d.k2 * d.k2 * S.RP;
-            d.bp_off = P.cells;                                      // range-local for now
+            const int64_t units = ((d.bp_wide ? 2 * ncell : ncell) + 1) & ~(int64_t)1;
+            S.level_units[l] = units;
+            d.bp_off = P.units;                                      // range-local for now
+            P.units += units;
             P.cells += ncell;
             P.max_level_cells = std::max(P.max_level_cells, ncell);
+            P.max_level_units = std::max(P.max_level_units, units);
             P.edge_pairs += (uint64_t)d.T * (uint64_t)d.T;
             if (has_col[l - 1] || has_col[l]) {
                 d.delta_off = P.delta_entries;                       // range-local for now
@@ -1161,21 +1224,23 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         }
     });
     // serial prefix over the ranges, then every range shifts its levels and copies its vectors into place
-    std::vector<int64_t> b_grp(NT + 1, 0), b_dead(NT + 1, 0), b_slot(NT + 1, 0), b_cells(NT + 1, 0), b_delta(NT + 1, DELTA_PAD), b_blk(NT + 1, 0), b_dt(NT + 1, 0);
+    std::vector<int64_t> b_grp(NT + 1, 0), b_dead(NT + 1, 0), b_slot(NT + 1, 0), b_cells(NT + 1, 0), b_units(NT + 1, 0), b_delta(NT + 1, DELTA_PAD), b_blk(NT + 1, 0), b_dt(NT + 1, 0);
     for (int t = 0; t < NT; ++t) {
         const Part &P = part[t];
         b_grp[t + 1] = b_grp[t] + (int64_t)P.grp_begin.size();
         b_dead[t + 1] = b_dead[t] + (int64_t)P.dead_cols.size();
         b_slot[t + 1] = b_slot[t] + (int64_t)P.slots.size() / 2;
         b_cells[t + 1] = b_cells[t] + P.cells;
+        b_units[t + 1] = b_units[t] + P.units;
         b_delta[t + 1] = b_delta[t] + P.delta_entries;
         b_blk[t + 1] = b_blk[t] + P.nblk;
         b_dt[t + 1] = b_dt[t] + (int64_t)P.dtrans.size();
         S.max_level_cells = std::max(S.max_level_cells, P.max_level_cells);
+        S.max_level_units = std::max(S.max_level_units, P.max_level_units);
         S.edge_pairs += P.edge_pairs;
         S.colour_entries += P.colour_entries;
     }
-    S.total_cells = b_cells[NT];
+    S.total_units = b_units[NT];
     S.cells = (uint64_t)b_cells[NT];
     S.delta_entries = b_delta[NT];
     const int64_t nblk = b_blk[NT];
@@ -1191,7 +1256,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             d.grp_first += (int32_t)b_grp[t];
             d.dead_first += (int32_t)b_dead[t];
             d.slot_first += b_slot[t];
-            d.bp_off += b_cells[t];
+            d.bp_off += b_units[t];
             if (d.delta_off >= 0) d.delta_off += b_delta[t];
         }
         std::copy(P.grp_begin.begin(), P.grp_begin.end(), grp_begin.begin() + b_grp[t]);
@@ -1211,7 +1276,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     size_t free_b = 0, total_b = 0;
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t pool_bytes;
-    { std::unique_lock<std::mutex> lk(S.pool.mu); pool_bytes = S.pool.chunks.size() * S.pool.chunk_cells * 4; }
+    { std::unique_lock<std::mutex> lk(S.pool.mu); pool_bytes = S.pool.chunks.size() * S.pool.chunk_units * 2; }
     const size_t have = free_b + pool_bytes + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes + S.d_ckpt.bytes;
     const size_t fixed = st_bytes + dl_bytes + 64 * (size_t)nV + ((size_t)2 << 30);     // state, delta, tables, slack
     if (fixed > have) {
@@ -1219,47 +1284,47 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         return DG_ERR_OOM;
     }
     // resident mode: levels packed into equal chunks (a level never straddles two)
-    size_t chunk_cells = S.pool.chunk_cells;
-    if ((size_t)S.max_level_cells > chunk_cells) chunk_cells = (size_t)S.max_level_cells;
+    size_t chunk_units = S.pool.chunk_units;
+    if ((size_t)S.max_level_units > chunk_units) chunk_units = (size_t)S.max_level_units;
     S.chunk_begin.assign(1, 1);
     {
         size_t acc = 0;
         for (int l = 1; l < L; ++l) {
-            const size_t ncell = (size_t)S.descs[l].k2 * S.descs[l].k2 * S.RP;
-            if (acc > 0 && acc + ncell > chunk_cells) { S.chunk_begin.push_back(l); acc = 0; }
-            acc += ncell;
+            const size_t nu = (size_t)S.level_units[l];
+            if (acc > 0 && acc + nu > chunk_units) { S.chunk_begin.push_back(l); acc = 0; }
+            acc += nu;
         }
         S.chunk_begin.push_back(L);
     }
     const size_t n_chunks = S.chunk_begin.size() - 1;
-    const size_t resident_bytes = n_chunks == 1 ? (size_t)S.total_cells * 4 : n_chunks * chunk_cells * 4;
+    const size_t resident_bytes = n_chunks == 1 ? (size_t)S.total_units * 2 : n_chunks * chunk_units * 2;
     bool segmented = resident_bytes + fixed > have || S.segment_cells > 0;
-    int64_t seg_cap_cells = (int64_t)((have - fixed) / 4);                            // back-pointer cells that fit
+    int64_t seg_cap_units = (int64_t)((have - fixed) / 2);                            // back-pointer units that fit
     if (segmented) {
         // keep half of the room for the checkpoints; a segment must hold at least its largest level
-        seg_cap_cells = S.segment_cells > 0 ? S.segment_cells : seg_cap_cells / 2;
-        seg_cap_cells = std::max<int64_t>(seg_cap_cells, S.max_level_cells);
+        seg_cap_units = S.segment_cells > 0 ? S.segment_cells : seg_cap_units / 2;
+        seg_cap_units = std::max<int64_t>(seg_cap_units, S.max_level_units);
     }
     S.seg_begin.assign(1, 1);
     S.ckpt_off.assign(1, 0);
-    int64_t max_seg_cells = 0, ckpt_cells = 0;
+    int64_t max_seg_units = 0, ckpt_cells = 0;
     if (segmented) {
         int64_t acc = 0;
         for (int l = 1; l < L; ++l) {
-            const int64_t ncell = (int64_t)S.descs[l].k2 * S.descs[l].k2 * S.RP;
-            if (acc > 0 && acc + ncell > seg_cap_cells) {
+            const int64_t nu = S.level_units[l];
+            if (acc > 0 && acc + nu > seg_cap_units) {
                 S.seg_begin.push_back(l);
                 S.ckpt_off.push_back(ckpt_cells);
                 ckpt_cells += (int64_t)S.descs[l].k * S.descs[l].k * S.RP;            // state of level l-1
-                max_seg_cells = std::max(max_seg_cells, acc);
+                max_seg_units = std::max(max_seg_units, acc);
                 acc = 0;
             }
-            acc += ncell;
+            acc += nu;
         }
-        max_seg_cells = std::max(max_seg_cells, acc);
+        max_seg_units = std::max(max_seg_units, acc);
     }
     S.seg_begin.push_back(L);
-    const size_t bp_bytes = segmented ? (size_t)max_seg_cells * 4 : 0, ck_bytes = (size_t)ckpt_cells * 4;
+    const size_t bp_bytes = segmented ? (size_t)max_seg_units * 2 : 0, ck_bytes = (size_t)ckpt_cells * 4;
     if (segmented) {
         pool_clear(S);                                        // the segment buffer takes the room instead
         if (bp_bytes + ck_bytes + fixed > have) {
@@ -1267,22 +1332,22 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             return DG_ERR_OOM;
         }
         if (dbg)
-            fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_cells * 4 / 1e9,
+            fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_units * 2 / 1e9,
                     S.seg_begin.size() - 1, bp_bytes / 1e9, ck_bytes / 1e9);
     } else {
         S.d_bp.release();
-        if (n_chunks == 1 && (size_t)S.total_cells < S.pool.chunk_cells / 8) {
+        if (n_chunks == 1 && (size_t)S.total_units < S.pool.chunk_units / 8) {
             // small lattice: one exact allocation instead of an 8 GB chunk
             pool_clear(S);
             { std::unique_lock<std::mutex> lk(S.pool.mu); }
-            if (int rc = S.d_bp.ensure((size_t)S.total_cells * 4)) return rc;
+            if (int rc = S.d_bp.ensure((size_t)S.total_units * 2)) return rc;
         } else {
-            if (chunk_cells != S.pool.chunk_cells) { pool_clear(S); S.pool.chunk_cells = chunk_cells; }
+            if (chunk_units != S.pool.chunk_units) { pool_clear(S); S.pool.chunk_units = chunk_units; }
             // surplus chunks of an over-estimated reservation stay unless the other buffers need their room
-            const size_t mapped = pool_bytes / (chunk_cells * 4);
+            const size_t mapped = pool_bytes / (chunk_units * 2);
             if (mapped > n_chunks && free_b < fixed) pool_trim(S, n_chunks);
             pool_request(S, c->device, n_chunks);        // returns at once; dp_run waits chunk by chunk
-            if (dbg) fprintf(stderr, "[dipgenie_hip] lattice: %zu chunks of %.1f GB, %zu mapped so far\n", n_chunks, chunk_cells * 4 / 1e9, mapped);
+            if (dbg) fprintf(stderr, "[dipgenie_hip] lattice: %zu chunks of %.1f GB, %zu mapped so far\n", n_chunks, chunk_units * 2 / 1e9, mapped);
         }
     }
     PoolPause pause(S);                                         // until the allocations below are done
@@ -1365,7 +1430,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
 
     // Sweeps destination levels [lb, le).  bp_biased = lattice pointer minus the offset of level lb's first cell
     // (so the kernels keep using the global LevelDesc::bp_off), or nullptr for a value-only pass.
-    auto sweep_range = [&](int lb, int le, uint32_t *bp_biased) -> int {
+    auto sweep_range = [&](int lb, int le, uint16_t *bp_biased) -> int {
         A.bp = bp_biased; F.bp = bp_biased;
         // runs of narrow levels may go to the one-XCD team kernel (one launch per run, optional); every other level
         // gets one whole-chip launch
@@ -1403,7 +1468,10 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                 continue;
             }
             for (int l = seg.begin; l < seg.end; ++l) {
-                const LevelDesc &d = S.descs[l];
+                LevelDesc &d = S.descs[l];
+                // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
+                // non-temporal ones that keep the once-written lattice out of the L2
+                d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
                 if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
                     // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
                     // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
@@ -1446,13 +1514,18 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         return (size_t)(k * k * S.RP);
     };
     const int n_seg = (int)S.seg_begin.size() - 1;
+    auto warm_rows = [&](int lb, int le) {              // row records of destination levels [lb, le), at most ~200 MB worth
+        const int64_t v0 = S.descs[lb].b0, v1 = (int64_t)S.descs[le - 1].b0 + S.descs[le - 1].k2;
+        const int64_t n = std::min<int64_t>(v1 - v0, (int64_t)12 << 20);
+        if (n > 0 && S.warm_rows) hipLaunchKernelGGL(dp_warm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S.d_rowrec.as<uint4>() + (v1 - n), n);
+    };
 
     // Launches issued while the pool thread is still mapping chunks would each queue behind a multi-GB hipMalloc,
     // so there is nothing to overlap: wait for the whole lattice first.
     if (n_seg == 1 && !S.d_bp.p) {
         const double tw0 = wall_s();
         const size_t n_chunks = S.chunk_begin.size() - 1;
-        if (!pool_wait(S, n_chunks - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_cells * 4 / 1e9); return DG_ERR_OOM; }
+        if (!pool_wait(S, n_chunks - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
         if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: waited %.3f s for lattice chunks\n", wall_s() - tw0);
     }
 retry_forward:
@@ -1470,19 +1543,21 @@ retry_forward:
     if (n_seg == 1) {
         // whole lattice resident (in chunks): one sweep with back-pointers, then the chain walk chunk by chunk, last first
         const int n_chunks = S.d_bp.p ? 1 : (int)S.chunk_begin.size() - 1;
-        std::vector<uint32_t *> biased(n_chunks);
+        std::vector<uint16_t *> biased(n_chunks);
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
-            uint32_t *base = S.d_bp.p ? S.d_bp.as<uint32_t>() : (uint32_t *)pool_wait(S, (size_t)ch);
-            if (!base) { set_error("back-pointer lattice: hipMalloc of chunk %d (%.1f GB) failed", ch, S.pool.chunk_cells * 4 / 1e9); return DG_ERR_OOM; }
+            uint16_t *base = S.d_bp.p ? S.d_bp.as<uint16_t>() : (uint16_t *)pool_wait(S, (size_t)ch);
+            if (!base) { set_error("back-pointer lattice: hipMalloc of chunk %d (%.1f GB) failed", ch, S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
             biased[ch] = base - S.descs[lb].bp_off;
             if (int rc = sweep_range(lb, le, biased[ch])) return rc;
         }
         DG_HIP(hipEventRecord(S.ev[2], s));
         for (int ch = n_chunks - 1; ch >= 0; --ch) {
             const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            warm_rows(lb, le);
             hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch],
-                               ch == n_chunks - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+                               ch == n_chunks - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
+                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
         }
     } else {
         // pass 1: values only, keeping the state in front of every segment
@@ -1501,10 +1576,12 @@ retry_forward:
                 DG_HIP(hipMemcpyAsync(state_ptr(lb - 1), S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], 4 * level_cells(lb - 1), hipMemcpyDeviceToDevice, s));
             else
                 hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
-            uint32_t *bp_biased = S.d_bp.as<uint32_t>() - S.descs[lb].bp_off;
+            uint16_t *bp_biased = S.d_bp.as<uint16_t>() - S.descs[lb].bp_off;
             if (int rc = sweep_range(lb, le, bp_biased)) { S.want_digest = dig; return rc; }
+            warm_rows(lb, le);
             hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, bp_biased,
-                               sg == n_seg - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+                               sg == n_seg - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
+                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
         }
         S.want_digest = dig;
         DG_HIP(hipEventRecord(S.ev[2], s));
@@ -1581,7 +1658,7 @@ extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
     if (int rc = dgi::bind(c)) return rc;
     if (!c->dp) c->dp = new dgi::DpState();
     dgi::DpState &S = *c->dp;
-    const size_t chunk_bytes = S.pool.chunk_cells * 4;
+    const size_t chunk_bytes = S.pool.chunk_units * 2;
     if (S.pool.cap_chunks == 0) {          // first call only: later ones may arrive while chunks are being mapped
         size_t free_b = 0, total_b = 0;
         DG_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1614,11 +1691,13 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "warm_rows")) c->dp->warm_rows = v;
+    else if (!strcmp(key, "bp_nt_min_cells")) c->dp->bp_nt_min_cells = v;
     else if (!strcmp(key, "host_threads")) c->dp->host_threads = v < 1 ? 1 : v;
-    else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (default 2^31 cells = 8 GB)
+    else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (in 16-bit back-pointer units = cells on ordinary levels; default 2^32 = 8 GB)
         if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
         dgi::pool_clear(*c->dp);
-        c->dp->pool.chunk_cells = (size_t)v;
+        c->dp->pool.chunk_units = ((size_t)v + 1) & ~(size_t)1;
     }
     else if (!strcmp(key, "waves_per_block")) c->dp->waves_per_block = (v >= 1 && v <= 4) ? v : 4;
     else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;

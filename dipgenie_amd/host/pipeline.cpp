@@ -273,27 +273,61 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
     std::vector<std::vector<int32_t>> ids(num_walks);
+    for (uint32_t h = 0; h < num_walks; ++h) ids[h].resize(kmer_index[h].hash.size());
+    {
+        // (haplotype, block of minimizers) work items: 24 whole haplotypes do not balance over 16+ threads
+        const size_t BLK = 1 << 15;
+        std::vector<std::pair<uint32_t, size_t>> items;
+        for (uint32_t h = 0; h < num_walks; ++h)
+            for (size_t m0 = 0; m0 < kmer_index[h].hash.size(); m0 += BLK) items.emplace_back(h, m0);
 #pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
-    for (int32_t h = 0; h < (int32_t)num_walks; ++h) {
-        auto &ix = kmer_index[h];
-        ids[h].resize(ix.hash.size());
-        for (size_t m = 0; m < ix.hash.size(); ++m) {
-            auto it = std::lower_bound(sp_hash.begin(), sp_hash.end(), ix.hash[m]);
-            ids[h][m] = (it != sp_hash.end() && *it == ix.hash[m]) ? (int32_t)(it - sp_hash.begin()) : -1;
+        for (int64_t it = 0; it < (int64_t)items.size(); ++it) {
+            const uint32_t h = items[it].first;
+            const auto &ix = kmer_index[h];
+            const size_t m1 = std::min(ix.hash.size(), items[it].second + BLK);
+            for (size_t m = items[it].second; m < m1; ++m) {
+                auto itp = std::lower_bound(sp_hash.begin(), sp_hash.end(), ix.hash[m]);
+                ids[h][m] = (itp != sp_hash.end() && *itp == ix.hash[m]) ? (int32_t)(itp - sp_hash.begin()) : -1;
+            }
         }
     }
     lap_a("dictionary lookup");
-    for (uint32_t h = 0; h < num_walks; ++h)
-        for (int32_t id : ids[h]) if (id >= 0) bucket_off[id + 1]++;
-    for (int32_t r = 0; r < count_sp_r; ++r) bucket_off[r + 1] += bucket_off[r];
-    std::vector<Raw> raw((size_t)bucket_off[count_sp_r]);
-    {
+    // stable counting sort of the (h, m) sequence by id: one histogram per haplotype, offsets in (id, h) order,
+    // every haplotype then scatters its own minimizers -- (h asc, minimizer order asc) inside every id
+    std::vector<Raw> raw;
+    if ((size_t)num_walks * (size_t)count_sp_r > ((size_t)1 << 29)) {   // histograms would not fit comfortably: serial sort
+        for (uint32_t h = 0; h < num_walks; ++h)
+            for (int32_t id : ids[h]) if (id >= 0) bucket_off[id + 1]++;
+        for (int32_t r = 0; r < count_sp_r; ++r) bucket_off[r + 1] += bucket_off[r];
+        raw.resize((size_t)bucket_off[count_sp_r]);
         std::vector<int64_t> fill(bucket_off.begin(), bucket_off.end() - 1);
-        for (uint32_t h = 0; h < num_walks; ++h)       // (h asc, minimizer order asc) inside every id
+        for (uint32_t h = 0; h < num_walks; ++h)
             for (size_t m = 0; m < ids[h].size(); ++m)
                 if (ids[h][m] >= 0) raw[fill[ids[h][m]]++] = Raw{(int32_t)h, (uint32_t)m};
+    } else {
+        const size_t NS = (size_t)count_sp_r;
+        std::vector<int32_t> cnt((size_t)num_walks * NS, 0);           // cnt[h][id]
+#pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
+        for (int32_t h = 0; h < (int32_t)num_walks; ++h) {
+            int32_t *c = cnt.data() + (size_t)h * NS;
+            for (int32_t id : ids[h]) if (id >= 0) c[id]++;
+        }
+        int64_t run = 0;
+        for (size_t r = 0; r < NS; ++r) {                              // exclusive prefix in (id, h) order
+            bucket_off[r] = run;
+            for (uint32_t h = 0; h < num_walks; ++h) { int32_t &c = cnt[(size_t)h * NS + r]; const int32_t n = c; c = (int32_t)(run - bucket_off[r]); run += n; }
+        }
+        bucket_off[NS] = run;
+        raw.resize((size_t)run);
+#pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
+        for (int32_t h = 0; h < (int32_t)num_walks; ++h) {
+            int32_t *c = cnt.data() + (size_t)h * NS;                  // now: offset of (id, h) inside bucket id
+            for (size_t m = 0; m < ids[h].size(); ++m) {
+                const int32_t id = ids[h][m];
+                if (id >= 0) raw[(size_t)(bucket_off[id] + c[id]++)] = Raw{h, (uint32_t)m};
+            }
+        }
     }
-
     lap_a("bucket by id");
     // ---- shared-anchor filter (:590-633) + occurrence sort (:641-663) ----
     occs.clear(); vpool.clear();

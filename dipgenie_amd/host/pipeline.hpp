@@ -15,6 +15,8 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <initializer_list>
+#include <utility>
 #include <vector>
 
 #include "../../include/dipgenie_hip.h"
@@ -68,9 +70,33 @@ struct ExpandedGraph {
     void permute(const std::vector<int32_t> &order);   // new vertex i = old vertex order[i]
 };
 
+// colour list of an anchor record: nearly always one entry (its own colour), a few more after containment
+// propagation -- two inline slots, heap only beyond (millions of records at MHC scale)
+class ColourList {
+    int inl_[2] = {0, 0};
+    uint32_t n_ = 0;
+    std::vector<int> *more_ = nullptr;
+    void spill() { more_ = new std::vector<int>(inl_, inl_ + n_); }
+public:
+    ColourList() = default;
+    ColourList(std::initializer_list<int> il) { for (int c : il) push_back(c); }
+    ColourList(const ColourList &o) : n_(o.n_), more_(o.more_ ? new std::vector<int>(*o.more_) : nullptr) { inl_[0] = o.inl_[0]; inl_[1] = o.inl_[1]; }
+    ColourList(ColourList &&o) noexcept : n_(o.n_), more_(o.more_) { inl_[0] = o.inl_[0]; inl_[1] = o.inl_[1]; o.more_ = nullptr; o.n_ = 0; }
+    ColourList &operator=(ColourList o) noexcept { std::swap(inl_[0], o.inl_[0]); std::swap(inl_[1], o.inl_[1]); std::swap(n_, o.n_); std::swap(more_, o.more_); return *this; }
+    ~ColourList() { delete more_; }
+    void push_back(int c) {
+        if (!more_ && n_ < 2) { inl_[n_++] = c; return; }
+        if (!more_) spill();
+        more_->push_back(c); ++n_;
+    }
+    const int *begin() const { return more_ ? more_->data() : inl_; }
+    const int *end() const { return begin() + n_; }
+    size_t size() const { return n_; }
+};
+
 struct AnchorRec {            // approximator.h:11-18
     int startOrg, endOrg, startExp, endExp;
-    std::vector<int> colours;
+    ColourList colours;
     int nodeID;
 };
 

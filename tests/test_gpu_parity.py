@@ -180,9 +180,11 @@ def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
         gpu_ctx.dp_set_option("lattice_chunk_cells", 1 << 31)
 
 
-def test_dp_giant_indegree_uses_generic_path(gpu_ctx):
-    """a vertex with in-degree > 64 (more than 64 haplotypes recombining into one vertex) leaves the fast path"""
-    k = 90
+@pytest.mark.parametrize("k", [90, 255, 256, 300])
+def test_dp_giant_indegree_uses_generic_path(gpu_ctx, k):
+    """a vertex with in-degree > 64 (more than 64 haplotypes recombining into one vertex) takes the general task
+    variant; beyond 255 the 8-bit in-edge ranks of the back-pointers overflow and the level keeps wide words on the
+    generic kernel"""
     level_off = np.array([0, 1, 1 + k, 2 + k, 3 + k], np.int32)
     out, w = [], []
     out_off = [0]
