@@ -46,6 +46,22 @@ __global__ void wr_b32_heads(uint32_t *p, size_t nrows, int seg, int nt) {
         if (lane % 3 == 0 && lane / 3 < seg) { if (nt) __builtin_nontemporal_store((uint32_t)r, &p[r * seg + lane / 3]); else p[r * seg + lane / 3] = (uint32_t)r; }
 }
 
+// the 16-bit back-pointer stream: 2 B per lane plain / non-temporal, and segment heads only
+__global__ void wr_b16(uint16_t *p, size_t n, int nt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (nt) asm volatile("global_store_short %0, %1, off nt" ::"v"(p + i), "v"((uint32_t)i) : "memory"); else p[i] = (uint16_t)i;
+    }
+}
+__global__ void wr_b16_heads(uint16_t *p, size_t nrows, int seg, int nt) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < nrows; r += nw)
+        if (lane % 3 == 0 && lane / 3 < seg) {
+            uint16_t *q = &p[r * seg + lane / 3];
+            if (nt) asm volatile("global_store_short %0, %1, off nt" ::"v"(q), "v"((uint32_t)r) : "memory"); else *q = (uint16_t)r;
+        }
+}
+
 int main() {
     void *buf = nullptr; uint32_t *sink = nullptr;
     CK(hipMalloc(&buf, GIB)); CK(hipMalloc(&sink, 4));
@@ -59,6 +75,10 @@ int main() {
     hipLaunchKernelGGL(wr_b32_nt, grid, block, 0, 0, (uint32_t *)buf, GIB / 4); CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(wr_b32_heads, grid, block, 0, 0, (uint32_t *)buf, GIB / 4 / 21, 21, 0); CK(hipDeviceSynchronize());
     hipLaunchKernelGGL(wr_b32_heads, grid, block, 0, 0, (uint32_t *)buf, GIB / 4 / 21, 21, 1); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(wr_b16, grid, block, 0, 0, (uint16_t *)buf, GIB / 2, 0); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(wr_b16, grid, block, 0, 0, (uint16_t *)buf, GIB / 2, 1); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(wr_b16_heads, grid, block, 0, 0, (uint16_t *)buf, GIB / 2 / 21, 21, 0); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(wr_b16_heads, grid, block, 0, 0, (uint16_t *)buf, GIB / 2 / 21, 21, 1); CK(hipDeviceSynchronize());
     printf("done: every kernel moved 1 GiB (the *_seg / *_heads ones %zu bytes)\n", (GIB / 4 / 21) * 21 * 4);
     return 0;
 }
