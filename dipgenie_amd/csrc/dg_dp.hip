@@ -420,8 +420,8 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     if (du <= 2) {
         // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
         if (act && du > 0) {
-            const int ia = (int)(rr.z & 0x7FFFFFFFu), wa = (int)(rr.z >> 31) + wv;
-            const int ib = (int)(rr.w & 0x7FFFFFFFu), wb = (int)(rr.w >> 31) + wv;
+            const int ia = (int)(rr.z & 0x7FFFu), wa = (int)(rr.z >> 31) + wv;    // (bit 16: flag for the chain walk)
+            const int ib = (int)(rr.w & 0x7FFFu), wb = (int)(rr.w >> 31) + wv;
             const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
             const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
             int va[RC], vb[RC];
@@ -561,8 +561,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
         if (du <= 2) {
             // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
             if (actb && du > 0) {
-                const int ia = (int)(rr.z & 0x7FFFFFFFu), wa = (int)(rr.z >> 31) + wv;
-                const int ib = (int)(rr.w & 0x7FFFFFFFu), wb = (int)(rr.w >> 31) + wv;
+                const int ia = (int)(rr.z & 0x7FFFu), wa = (int)(rr.z >> 31) + wv;
+                const int ib = (int)(rr.w & 0x7FFFu), wb = (int)(rr.w >> 31) + wv;
                 const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
                 const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
                 int va[RC], vb[RC];
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
                                                             const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
                                                             uint32_t *__restrict__ path, ChainState *st) {
     const int lane = threadIdx.x & 63;
-    int i, j, r, value;
+    int i, j, r, value, forced = 0;                                     // forced: bit 0 row, bit 1 column has one in-edge
     if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; i = 0; j = 0; r = R; }   // sink level, layout [i][r][j]: cell (0, R, 0)
     else { i = st->i; j = st->j; r = st->r; value = st->value; }
     if (value != NEG_INF) {
@@ -842,21 +842,30 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
                 uint32_t hop;
                 if (bw < 0) {                                           // wide level: the hop word itself
                     hop = *(const uint32_t *)(bp + bo_l + 2 * cell);
+                    forced = 0;
                 } else {
                     // One round trip: the back-pointer and the two row records go out together (even lanes fetch the
                     // row's record, odd lanes the column's -- lane-varying addresses, so the compiler can neither turn
                     // them into scalar loads nor defer them behind the back-pointer); ranks 0 and 1 (97 % of the
-                    // vertices) are inside the record, higher ranks cost one more load.
+                    // vertices) are inside the record, higher ranks cost one more load.  When the previous hop said that
+                    // row and column both have a single in-edge the winner is (0, 0) whatever the lattice says: no
+                    // back-pointer load, the step costs an Infinity-Cache hit instead of an HBM miss.
                     const int odd = lane & 1;
                     const uint4 rr = rowrec[bw + (odd ? j : i)];
-                    const uint32_t b = bp[bo_l + cell];
-                    uint32_t e0 = rr.x;
-                    asm volatile("" : "+v"(e0));                        // keep the whole record in the first round trip
-                    const uint32_t rank = odd ? (b & 0xFFu) : (b >> 8);
-                    uint32_t p = rank == 0 ? rr.z : rr.w;
-                    if (rank > 1) p = in_edge[e0 + rank];
+                    uint32_t p;
+                    if (forced == 3) {
+                        p = rr.z;
+                    } else {
+                        const uint32_t b = bp[bo_l + cell];
+                        uint32_t e0 = rr.x;
+                        asm volatile("" : "+v"(e0));                    // keep the whole record in the first round trip
+                        const uint32_t rank = odd ? (b & 0xFFu) : (b >> 8);
+                        p = rank == 0 ? rr.z : rr.w;
+                        if (rank > 1) p = in_edge[e0 + rank];           // (no flag bit in the full in-edge array)
+                    }
                     const uint32_t pu = (uint32_t)__builtin_amdgcn_readlane((int)p, 0), pv = (uint32_t)__builtin_amdgcn_readlane((int)p, 1);
                     hop = (pu & 0x7FFFu) | ((pv & 0x7FFFu) << 15) | ((pu >> 31) << 30) | ((pv >> 31) << 31);
+                    forced = (int)((pu >> 16) & 1u) | (int)(((pv >> 16) & 1u) << 1);
                 }
                 if (lane == 0) path[l] = hop;
                 i = (int)(hop & 0x7FFFu); j = (int)((hop >> 15) & 0x7FFFu);
@@ -1122,7 +1131,18 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         for (int v = va; v < vb; ++v) {
             const uint32_t e0 = in_off[v], dv = in_off[v + 1] - e0;
             rowrec[4 * (size_t)v] = e0; rowrec[4 * (size_t)v + 1] = dv;
-            rowrec[4 * (size_t)v + 2] = dv > 0 ? in_edge[e0] : 0; rowrec[4 * (size_t)v + 3] = dv > 1 ? in_edge[e0 + 1] : 0;
+            // in-edges 0 and 1 ride along; bit 16 of each says "the source vertex has exactly one in-edge itself", which
+            // lets the chain walk skip the back-pointer load at the next level when row and column are both forced
+            const int a0v = g->level_off[std::max(0, level_of[v] - 1)];
+            for (uint32_t q = 0; q < 2; ++q) {
+                uint32_t word = 0;
+                if (dv > q) {
+                    word = in_edge[e0 + q];
+                    const int src = a0v + (int)(word & 0x7FFFu);
+                    if (in_off[src + 1] - in_off[src] == 1) word |= 1u << 16;
+                }
+                rowrec[4 * (size_t)v + 2 + q] = word;
+            }
         }
         auto &grp_begin = P.grp_begin; auto &dead_cols = P.dead_cols; auto &slots = P.slots;
         for (int l = std::max(1, lcut[t]); l < lcut[t + 1]; ++l) {
