@@ -97,6 +97,8 @@ struct DpState {
         std::thread th;
     } pool;
     std::vector<int> chunk_begin;              // destination levels [chunk_begin[c], chunk_begin[c+1]) live in chunk c
+    size_t chunk_units_cfg = (size_t)4 << 30;  // configured chunk size (option lattice_chunk_cells); pool.chunk_units = the live pool's
+    int seg_chunks = 1;                        // chunks per lattice segment (= all of them when the lattice is resident)
 };
 
 void dp_state_free(DpState *s) {
@@ -1303,8 +1305,11 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         set_error("graph needs %.1f GB of HBM for state/delta/tables but only %.1f GB is free", fixed / 1e9, have / 1e9);
         return DG_ERR_OOM;
     }
-    // resident mode: levels packed into equal chunks (a level never straddles two)
-    size_t chunk_units = S.pool.chunk_units;
+    // Levels are packed into equal chunks (a level never straddles two).  If all chunks fit they stay resident;
+    // otherwise a segment = as many consecutive chunks as fit (pool chunks are reused by every segment) and the run
+    // goes checkpoint + recompute.  segment_cells (tests) caps the chunk size and forces one chunk per segment.
+    size_t chunk_units = S.chunk_units_cfg;
+    if (S.segment_cells > 0) chunk_units = std::min(chunk_units, ((size_t)S.segment_cells + 1) & ~(size_t)1);
     if ((size_t)S.max_level_units > chunk_units) chunk_units = (size_t)S.max_level_units;
     S.chunk_begin.assign(1, 1);
     {
@@ -1317,58 +1322,57 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         S.chunk_begin.push_back(L);
     }
     const size_t n_chunks = S.chunk_begin.size() - 1;
-    const size_t resident_bytes = n_chunks == 1 ? (size_t)S.total_units * 2 : n_chunks * chunk_units * 2;
-    bool segmented = resident_bytes + fixed > have || S.segment_cells > 0;
-    int64_t seg_cap_units = (int64_t)((have - fixed) / 2);                            // back-pointer units that fit
-    if (segmented) {
-        // keep half of the room for the checkpoints; a segment must hold at least its largest level
-        seg_cap_units = S.segment_cells > 0 ? S.segment_cells : seg_cap_units / 2;
-        seg_cap_units = std::max<int64_t>(seg_cap_units, S.max_level_units);
+    const bool tiny = n_chunks == 1 && (size_t)S.total_units < S.chunk_units_cfg / 8 && S.segment_cells == 0;   // one exact allocation
+    const size_t chunk_bytes = chunk_units * 2;
+    const size_t resident_bytes = tiny ? (size_t)S.total_units * 2 : n_chunks * chunk_bytes;
+    const bool segmented = (resident_bytes + fixed > have || S.segment_cells > 0) && n_chunks > 1;
+    if (!segmented && resident_bytes + fixed > have) {
+        set_error("back-pointer lattice of %.1f GB (one level alone needs %.1f GB) does not fit the %.1f GB of free HBM", resident_bytes / 1e9,
+                  S.max_level_units * 2 / 1e9, (have - fixed) / 1e9);
+        return DG_ERR_OOM;
     }
+    // chunks per segment: the most that fit beside the checkpoints (state in front of every segment)
+    size_t group = n_chunks;
     S.seg_begin.assign(1, 1);
     S.ckpt_off.assign(1, 0);
-    int64_t max_seg_units = 0, ckpt_cells = 0;
+    int64_t ckpt_cells = 0;
     if (segmented) {
-        int64_t acc = 0;
-        for (int l = 1; l < L; ++l) {
-            const int64_t nu = S.level_units[l];
-            if (acc > 0 && acc + nu > seg_cap_units) {
+        group = S.segment_cells > 0 ? 1 : std::max<size_t>(1, std::min(n_chunks - 1, (have - fixed) / chunk_bytes));
+        for (;; --group) {
+            S.seg_begin.assign(1, 1);
+            S.ckpt_off.assign(1, 0);
+            ckpt_cells = 0;
+            for (size_t cb = group; cb < n_chunks; cb += group) {
+                const int l = S.chunk_begin[cb];
                 S.seg_begin.push_back(l);
                 S.ckpt_off.push_back(ckpt_cells);
                 ckpt_cells += (int64_t)S.descs[l].k * S.descs[l].k * S.RP;            // state of level l-1
-                max_seg_units = std::max(max_seg_units, acc);
-                acc = 0;
             }
-            acc += nu;
+            if (group * chunk_bytes + (size_t)ckpt_cells * 4 + fixed <= have || group == 1) break;
         }
-        max_seg_units = std::max(max_seg_units, acc);
-    }
-    S.seg_begin.push_back(L);
-    const size_t bp_bytes = segmented ? (size_t)max_seg_units * 2 : 0, ck_bytes = (size_t)ckpt_cells * 4;
-    if (segmented) {
-        pool_clear(S);                                        // the segment buffer takes the room instead
-        if (bp_bytes + ck_bytes + fixed > have) {
-            set_error("segmented lattice needs %.1f GB (+%.1f GB checkpoints) but only %.1f GB of HBM is free", bp_bytes / 1e9, ck_bytes / 1e9, have / 1e9);
+        if (group * chunk_bytes + (size_t)ckpt_cells * 4 + fixed > have) {
+            set_error("segmented lattice needs %.1f GB (+%.1f GB checkpoints) but only %.1f GB of HBM is free", group * chunk_bytes / 1e9,
+                      ckpt_cells * 4 / 1e9, (have - fixed) / 1e9);
             return DG_ERR_OOM;
         }
         if (dbg)
-            fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %.1f GB, checkpoints %.2f GB\n", S.total_units * 2 / 1e9,
-                    S.seg_begin.size() - 1, bp_bytes / 1e9, ck_bytes / 1e9);
+            fprintf(stderr, "[dipgenie_hip] lattice %.1f GB does not fit: %zu segments of <= %zu chunks of %.1f GB, checkpoints %.2f GB\n",
+                    S.total_units * 2 / 1e9, S.seg_begin.size(), group, chunk_bytes / 1e9, ckpt_cells * 4 / 1e9);
+    }
+    S.seg_begin.push_back(L);
+    S.seg_chunks = (int)group;
+    const size_t bp_bytes = tiny ? resident_bytes : group * chunk_bytes, ck_bytes = (size_t)ckpt_cells * 4;
+    S.d_bp.release();
+    if (tiny) {
+        pool_clear(S);
+        if (int rc = S.d_bp.ensure((size_t)S.total_units * 2)) return rc;
     } else {
-        S.d_bp.release();
-        if (n_chunks == 1 && (size_t)S.total_units < S.pool.chunk_units / 8) {
-            // small lattice: one exact allocation instead of an 8 GB chunk
-            pool_clear(S);
-            { std::unique_lock<std::mutex> lk(S.pool.mu); }
-            if (int rc = S.d_bp.ensure((size_t)S.total_units * 2)) return rc;
-        } else {
-            if (chunk_units != S.pool.chunk_units) { pool_clear(S); S.pool.chunk_units = chunk_units; }
-            // surplus chunks of an over-estimated reservation stay unless the other buffers need their room
-            const size_t mapped = pool_bytes / (chunk_units * 2);
-            if (mapped > n_chunks && free_b < fixed) pool_trim(S, n_chunks);
-            pool_request(S, c->device, n_chunks);        // returns at once; dp_run waits chunk by chunk
-            if (dbg) fprintf(stderr, "[dipgenie_hip] lattice: %zu chunks of %.1f GB, %zu mapped so far\n", n_chunks, chunk_units * 2 / 1e9, mapped);
-        }
+        if (chunk_units != S.pool.chunk_units) { pool_clear(S); S.pool.chunk_units = chunk_units; pool_bytes = 0; }
+        // surplus chunks of an over-estimated reservation stay unless the other buffers need their room
+        const size_t mapped = pool_bytes / chunk_bytes;
+        if (mapped > group && free_b < fixed + ck_bytes) pool_trim(S, group);
+        pool_request(S, c->device, group);                      // returns at once; dp_run waits for the chunks
+        if (dbg) fprintf(stderr, "[dipgenie_hip] lattice: %zu chunks of %.1f GB (%zu resident at a time), %zu mapped so far\n", n_chunks, chunk_bytes / 1e9, group, mapped);
     }
     PoolPause pause(S);                                         // until the allocations below are done
     lap("plan lattice");
@@ -1390,7 +1394,6 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     lap("table uploads");
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
-    if (segmented) { if (int rc = S.d_bp.ensure(bp_bytes)) return rc; }
     if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
     if (int rc = S.d_chain.ensure(sizeof(ChainState))) return rc;
     S.pad_front = 2 * (int64_t)max_k;
@@ -1414,7 +1417,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     memset(&S.timing, 0, sizeof S.timing);
     S.timing.edge_pairs = S.edge_pairs;
     S.timing.colour_entries = S.colour_entries;
-    S.timing.state_bytes = st_bytes; S.timing.bp_bytes = segmented ? bp_bytes : resident_bytes; S.timing.delta_bytes = dl_bytes;
+    S.timing.state_bytes = st_bytes; S.timing.bp_bytes = bp_bytes; S.timing.delta_bytes = dl_bytes;
     (void)dtrans;
     S.loaded = true;
     return DG_OK;
@@ -1541,13 +1544,37 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     };
 
     // Launches issued while the pool thread is still mapping chunks would each queue behind a multi-GB hipMalloc,
-    // so there is nothing to overlap: wait for the whole lattice first.
-    if (n_seg == 1 && !S.d_bp.p) {
+    // so there is nothing to overlap: wait for every chunk this run uses first.
+    const int n_chunks_all = (int)S.chunk_begin.size() - 1;
+    std::vector<uint16_t *> pool_base;
+    if (!S.d_bp.p) {
         const double tw0 = wall_s();
-        const size_t n_chunks = S.chunk_begin.size() - 1;
-        if (!pool_wait(S, n_chunks - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
+        const size_t need = (size_t)std::min(S.seg_chunks, n_chunks_all);
+        if (!pool_wait(S, need - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
+        std::unique_lock<std::mutex> lk(S.pool.mu);
+        for (size_t q = 0; q < need; ++q) pool_base.push_back((uint16_t *)S.pool.chunks[q]);
         if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: waited %.3f s for lattice chunks\n", wall_s() - tw0);
     }
+    // Sweeps the chunks [c0, c1) with back-pointers into pool chunks 0 .. c1-c0-1 (or the one exact buffer), then walks
+    // them last first; from_sink = this is the walk that starts at the sink.
+    auto sweep_and_walk = [&](int c0, int c1, bool from_sink, bool mark_forward_end) -> int {
+        std::vector<uint16_t *> biased(c1 - c0);
+        for (int ch = c0; ch < c1; ++ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            uint16_t *base = S.d_bp.p ? S.d_bp.as<uint16_t>() : pool_base[ch - c0];
+            biased[ch - c0] = base - S.descs[lb].bp_off;
+            if (int rc = sweep_range(lb, le, biased[ch - c0])) return rc;
+        }
+        if (mark_forward_end) DG_HIP(hipEventRecord(S.ev[2], s));
+        for (int ch = c1 - 1; ch >= c0; --ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            warm_rows(lb, le);
+            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch - c0],
+                               from_sink && ch == c1 - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
+                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+        }
+        return DG_OK;
+    };
 retry_forward:
     n_launch = 0; team_used = false; team_err = 0;
     DG_HIP(hipEventRecord(S.ev[0], s));
@@ -1561,24 +1588,8 @@ retry_forward:
     if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
     hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
     if (n_seg == 1) {
-        // whole lattice resident (in chunks): one sweep with back-pointers, then the chain walk chunk by chunk, last first
-        const int n_chunks = S.d_bp.p ? 1 : (int)S.chunk_begin.size() - 1;
-        std::vector<uint16_t *> biased(n_chunks);
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
-            uint16_t *base = S.d_bp.p ? S.d_bp.as<uint16_t>() : (uint16_t *)pool_wait(S, (size_t)ch);
-            if (!base) { set_error("back-pointer lattice: hipMalloc of chunk %d (%.1f GB) failed", ch, S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
-            biased[ch] = base - S.descs[lb].bp_off;
-            if (int rc = sweep_range(lb, le, biased[ch])) return rc;
-        }
-        DG_HIP(hipEventRecord(S.ev[2], s));
-        for (int ch = n_chunks - 1; ch >= 0; --ch) {
-            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
-            warm_rows(lb, le);
-            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch],
-                               ch == n_chunks - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
-                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
-        }
+        // whole lattice resident: one sweep with back-pointers, then the chain walk chunk by chunk, last first
+        if (int rc = sweep_and_walk(0, S.d_bp.p ? 1 : n_chunks_all, true, true)) return rc;
     } else {
         // pass 1: values only, keeping the state in front of every segment
         const bool dig = S.want_digest;
@@ -1588,23 +1599,19 @@ retry_forward:
                                       4 * level_cells(S.seg_begin[sg] - 1), hipMemcpyDeviceToDevice, s));
             if (int rc = sweep_range(S.seg_begin[sg], S.seg_begin[sg + 1], nullptr)) return rc;
         }
-        // pass 2: last segment first -- restore its input state, re-sweep with back-pointers, walk it
+        DG_HIP(hipEventRecord(S.ev[2], s));                 // (the re-sweeps below are booked under traceback_ms)
+        // pass 2: last segment first -- restore its input state, re-sweep its chunks with back-pointers, walk them
         S.want_digest = 0;                                  // digests were accumulated in pass 1
         for (int sg = n_seg - 1; sg >= 0; --sg) {
-            const int lb = S.seg_begin[sg], le = S.seg_begin[sg + 1];
+            const int lb = S.seg_begin[sg];
             if (sg > 0)
                 DG_HIP(hipMemcpyAsync(state_ptr(lb - 1), S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], 4 * level_cells(lb - 1), hipMemcpyDeviceToDevice, s));
             else
                 hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
-            uint16_t *bp_biased = S.d_bp.as<uint16_t>() - S.descs[lb].bp_off;
-            if (int rc = sweep_range(lb, le, bp_biased)) { S.want_digest = dig; return rc; }
-            warm_rows(lb, le);
-            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, bp_biased,
-                               sg == n_seg - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
-                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+            const int c0 = sg * S.seg_chunks, c1 = std::min(n_chunks_all, c0 + S.seg_chunks);
+            if (int rc = sweep_and_walk(c0, c1, sg == n_seg - 1, false)) { S.want_digest = dig; return rc; }
         }
         S.want_digest = dig;
-        DG_HIP(hipEventRecord(S.ev[2], s));
     }
     hipLaunchKernelGGL(dp_trace_finish_kernel, dim3(1), dim3(1024), 0, s, descs, S.L, S.d_path.as<uint32_t>(), col, S.cap,
                        S.d_edges.as<int32_t>(), S.d_chain.as<ChainState>(), S.d_trace.as<TraceOut>());
@@ -1678,6 +1685,7 @@ extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
     if (int rc = dgi::bind(c)) return rc;
     if (!c->dp) c->dp = new dgi::DpState();
     dgi::DpState &S = *c->dp;
+    if (S.pool.chunk_units != S.chunk_units_cfg) { dgi::pool_clear(S); S.pool.chunk_units = S.chunk_units_cfg; }
     const size_t chunk_bytes = S.pool.chunk_units * 2;
     if (S.pool.cap_chunks == 0) {          // first call only: later ones may arrive while chunks are being mapped
         size_t free_b = 0, total_b = 0;
@@ -1717,7 +1725,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (in 16-bit back-pointer units = cells on ordinary levels; default 2^32 = 8 GB)
         if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
         dgi::pool_clear(*c->dp);
-        c->dp->pool.chunk_units = ((size_t)v + 1) & ~(size_t)1;
+        c->dp->chunk_units_cfg = c->dp->pool.chunk_units = ((size_t)v + 1) & ~(size_t)1;
     }
     else if (!strcmp(key, "waves_per_block")) c->dp->waves_per_block = (v >= 1 && v <= 4) ? v : 4;
     else if (!strcmp(key, "chip_waves")) c->dp->chip_waves = v > 0 ? v : 8192;

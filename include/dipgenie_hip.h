@@ -65,8 +65,9 @@ typedef struct dg_dp_result {         /* sink state at r = R (approximator.cpp:7
 
 typedef struct dg_dp_timing {         /* HIP-event times of the last dg_dp_run, milliseconds */
     float delta_ms;                   /* score-delta precompute kernel(s) */
-    float forward_ms;                 /* level sweep */
-    float traceback_ms;               /* back-pointer walk + edge-list extraction */
+    float forward_ms;                 /* level sweep (segmented lattice: the value-only first pass) */
+    float traceback_ms;               /* back-pointer walk + edge-list extraction (segmented lattice: plus the
+                                         re-sweeps of the segments with back-pointers) */
     float total_ms;                   /* first launch -> last kernel done */
     int64_t n_forward_launches;
     uint64_t edge_pairs;              /* sum over levels of (in-edges into level)^2 */

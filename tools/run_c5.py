@@ -13,10 +13,20 @@ print(f"generated: {len(segs)} segments, {len(walks)} walks, {len(reads)} reads 
 env = dict(os.environ, DG_DEBUG="1")
 for rep in range(2):
     t0 = time.time()
-    p = subprocess.run([f"{ROOT}/bin/DipGenie", "-t32", "-p2", f"-R{R}", "-g", f"{d}/c5.gfa", "-r", f"{d}/c5.fa", "-o", f"{d}/o{rep}.fa", "-J", f"{d}/o.json"],
+    p = subprocess.run([f"{ROOT}/bin/DipGenie", "-t16", "-p2", f"-R{R}", "-g", f"{d}/c5.gfa", "-r", f"{d}/c5.fa", "-o", f"{d}/o{rep}.fa", "-J", f"{d}/o.json"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     print(f"run {rep}: rc={p.returncode} wall {time.time()-t0:.2f}s")
     for line in p.stderr.decode().split("\n"):
         if any(k in line for k in ("stage]", "lattice", "dg::dp", "Real time", "[E::")): print("  ", line)
     if p.returncode == 0: print("  ", {k: v for k, v in json.load(open(f"{d}/o.json")).items() if k != "stages"})
 print("outputs identical:", open(f"{d}/o0.fa").read() == open(f"{d}/o1.fa").read())
+if len(sys.argv) > 4:      # also dump the levelized graph and keep a prefix window of it (kernel experiments)
+    subprocess.run([f"{ROOT}/bin/DipGenie", "-t16", "-p2", f"-R{R}", "-g", f"{d}/c5.gfa", "-r", f"{d}/c5.fa", "-o", f"{d}/o2.fa", "-D", f"{d}/c5"],
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    import bench
+    from dipgenie_amd import capi
+    g = capi.DpGraphArrays.load(f"{d}/c5.dpg")
+    gs, P = bench.truncated_graph(g, float(sys.argv[4]))
+    os.makedirs(f"{ROOT}/gpurun_out", exist_ok=True)
+    gs.save(f"{ROOT}/gpurun_out/win_c5.dpg")
+    print(f"window: first {P} of {g.n_levels} levels, {gs.n_vertices} vertices -> gpurun_out/win_c5.dpg ({os.path.getsize(ROOT + '/gpurun_out/win_c5.dpg') / 1e6:.1f} MB)")
