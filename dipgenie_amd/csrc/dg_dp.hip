@@ -59,7 +59,7 @@ struct DpState {
     int64_t want_digest = 0, use_fast = 1, use_team = 0, team_grid = 256, max_blocks = 1024, team_fallbacks = 0;
     int last_team_size = 0;
     bool all_fast = false;
-    int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 1, chip_waves = 8192, waves_per_block = 4;
+    int64_t team_max_tasks = 100, team_min_levels = 16, adaptive_rc = 3, chip_waves = 8192, waves_per_block = 4;
     // lattice segments: destination levels [seg_begin[s], seg_begin[s+1]); one segment = whole lattice resident.
     // More than one = checkpoint + recompute (value-only pass, then each segment re-swept with back-pointers, last first).
     std::vector<int> seg_begin;
@@ -77,6 +77,8 @@ struct DpState {
     int64_t total_units = 0, max_level_units = 0;       // back-pointer lattice, in 16-bit units (1 per cell, 2 on wide levels)
     int64_t max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
     std::vector<int64_t> level_units;                   // units of every level (even)
+    std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
+    int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 100;   // cost model of the per-level RC choice
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
     DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
     std::vector<uint64_t> digest_host;
@@ -1118,6 +1120,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.cells = S.relaxations = S.edge_pairs = S.colour_entries = 0;
     S.total_units = 0; S.max_level_units = 0; S.max_level_cells = S.RP; S.delta_entries = DELTA_PAD;
     S.level_units.assign(L, 0);
+    S.level_dmax.assign(L, 0);
     std::vector<uint32_t> rowrec((size_t)nV * 4, 0);
     struct Part {
         std::vector<int32_t> dtrans, dead_cols;
@@ -1174,6 +1177,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             d.fast_ok = (d.T < (1 << 20)) ? 1 : 0;                   // the slot word keeps 20 bits of in-edge index
             uint32_t max_indeg = 0;
             for (int c = 0; c < d.k2; ++c) max_indeg = std::max(max_indeg, in_off[d.b0 + c + 1] - in_off[d.b0 + c]);
+            S.level_dmax[l] = (int32_t)max_indeg;
             d.bp_wide = max_indeg > (uint32_t)BP_MAX_RANK ? 1 : 0;  // ranks do not fit 8 bits: wide words, generic kernel
             if (d.bp_wide) d.fast_ok = 0;
             int32_t n_blocks = 0;
@@ -1500,18 +1504,35 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                     // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
                     const int64_t base = (int64_t)d.k2 * d.nblocks;
                     int rc = rc_sel;
-                    if (S.adaptive_rc) {
+                    if (S.adaptive_rc == 1) {                             // first rule: smallest RC whose waves fit a budget
                         static const int cand[5] = {1, 2, 4, 8, 16};
                         for (int q = 0; q < 5; ++q)
                             if (cand[q] < rc_sel && base * ((S.RP + cand[q] - 1) / cand[q]) <= S.chip_waves) { rc = cand[q]; break; }
+                    } else if (S.adaptive_rc >= 2) {
+                        // Cost model fitted on MHC-24 (R = 18) and the 100-walk chr22-style panel (R = 32):
+                        //   T(RC) = max(1, W / cap) * (t0 + dmax * RC * tg) + W * tw,   W = tasks * ceil(RP / RC) waves.
+                        // First factor: rounds of resident waves; second: a wave's dependent chain (the row with the
+                        // largest in-degree walks dmax in-edges with RC gathers each); last: per-wave issue overhead.
+                        const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
+                        double best = 1e300;
+                        for (int q = 0; q < 11; ++q) {
+                            if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
+                            if (S.adaptive_rc == 2 && (cand[q] == 3 || cand[q] == 5 || cand[q] == 6 || cand[q] == 10 || cand[q] == 11)) continue;   // 3: all sizes
+                            const double W = (double)base * ((S.RP + cand[q] - 1) / cand[q]);
+                            const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + (double)std::max(1, S.level_dmax[l]) * cand[q] * (double)S.rc_tg_ps * 1e-3) +
+                                             W * (double)S.rc_tw_ps * 1e-3;
+                            if (T <= best) { best = T; rc = cand[q]; }        // ties: the larger RC (fewer waves)
+                        }
                     }
                     const int nch = (S.RP + rc - 1) / rc;
                     const int wpb = (int)S.waves_per_block;               // waves (= slot blocks) per workgroup
                     const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)(d.k2 * nch));
 #define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l); \
                               else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l); } while (0)
-#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 4: DG_FAST(4, DG); break; \
-                                        case 8: DG_FAST(8, DG); break; case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
+#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
+                                        case 4: DG_FAST(4, DG); break; case 5: DG_FAST(5, DG); break; case 6: DG_FAST(6, DG); break; \
+                                        case 8: DG_FAST(8, DG); break; case 10: DG_FAST(10, DG); break; case 11: DG_FAST(11, DG); break; \
+                                        case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
                                         default: DG_FAST(33, DG); break; } } while (0)
                     if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
 #undef DG_FAST_RC
@@ -1719,6 +1740,10 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "rc_cap")) c->dp->rc_cap = v > 0 ? v : 16384;
+    else if (!strcmp(key, "rc_t0_ns")) c->dp->rc_t0_ns = v;
+    else if (!strcmp(key, "rc_tg_ps")) c->dp->rc_tg_ps = v;
+    else if (!strcmp(key, "rc_tw_ps")) c->dp->rc_tw_ps = v;
     else if (!strcmp(key, "warm_rows")) c->dp->warm_rows = v;
     else if (!strcmp(key, "bp_nt_min_cells")) c->dp->bp_nt_min_cells = v;
     else if (!strcmp(key, "host_threads")) c->dp->host_threads = v < 1 ? 1 : v;

@@ -131,10 +131,11 @@ def test_dp_random_levelized(gpu_ctx, seed):
     _dp_both(gpu_ctx, g)
 
 
-@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive"])
+@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive", "budget_rc", "model_rc_pow2"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
     """the generic fallback sweep, the one-XCD team kernel and the fixed-RC launch must all give the oracle's answer"""
-    opts = {"generic": {"fast": 0}, "team": {"team": 1, "team_min_levels": 4, "team_max_tasks": 4096}, "no_adaptive": {"adaptive_rc": 0}}[mode]
+    opts = {"generic": {"fast": 0}, "team": {"team": 1, "team_min_levels": 4, "team_max_tasks": 4096}, "no_adaptive": {"adaptive_rc": 0},
+            "budget_rc": {"adaptive_rc": 1}, "model_rc_pow2": {"adaptive_rc": 2}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -145,7 +146,7 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             ref = orc.dp_solve(g)
             assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"]), (mode, seed)
     finally:
-        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 1}.items():
+        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 3}.items():
             gpu_ctx.dp_set_option(k, v)
 
 
