@@ -77,6 +77,13 @@ struct DpState {
     int64_t total_units = 0, max_level_units = 0;       // back-pointer lattice, in 16-bit units (1 per cell, 2 on wide levels)
     int64_t max_level_cells = 0, delta_entries = 0, n_delta_blocks = 0, pad_front = 0;
     std::vector<int64_t> level_units;                   // units of every level (even)
+    // score-delta windows: coloured transitions [dwin_t[w], dwin_t[w+1]) are resident together (one window = everything
+    // unless the matrices outgrow delta_cap_entries; then each window is recomputed right before its first level)
+    std::vector<int32_t> dwin_t, level_win;             // level_win[l] = window of level l's transition, -1 if colourless
+    int cur_win = -1;                                   // window whose matrices are in d_delta right now
+    std::vector<int32_t> dtrans_host;
+    std::vector<int64_t> dblk_first_host;
+    int64_t delta_cap_entries = (int64_t)4 << 30, delta_buf_entries = 0;
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 100;   // cost model of the per-level RC choice
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
@@ -163,11 +170,11 @@ __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restri
                                                        const int64_t *__restrict__ dblk_first,  // first block of each coloured transition
                                                        int n_dtrans, const uint32_t *__restrict__ in_edge,
                                                        const int32_t *__restrict__ in_dst, ColourCsr col,
-                                                       uint16_t *__restrict__ delta) {
+                                                       uint16_t *__restrict__ delta /* biased like SweepArgs::delta */, int64_t block0) {
     __shared__ int s_t;
     if (threadIdx.x == 0) {   // binary search: last transition whose first block <= blockIdx.x
         int lo = 0, hi = n_dtrans - 1;
-        const int64_t b = blockIdx.x;
+        const int64_t b = block0 + blockIdx.x;
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (dblk_first[mid] <= b) lo = mid; else hi = mid - 1; }
         s_t = lo;
     }
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restri
     const int t = s_t;
     const LevelDesc d = descs[dtrans[t]];
     const int64_t n = (int64_t)d.T * d.T;
-    const int64_t first = ((int64_t)blockIdx.x - dblk_first[t]) * DELTA_PER_BLOCK;
+    const int64_t first = (block0 + (int64_t)blockIdx.x - dblk_first[t]) * DELTA_PER_BLOCK;
     uint16_t *out = delta + d.delta_off;
     for (int q = 0; q < DELTA_PER_BLOCK / 256; ++q) {
         const int64_t e = first + q * 256 + threadIdx.x;
@@ -208,7 +215,7 @@ struct SweepArgs {
     const LevelDesc *descs;
     const uint32_t *in_off, *in_edge, *grp_begin;
     const int32_t *in_dst, *dead_cols;
-    const uint16_t *delta;
+    const uint16_t *delta, *delta_zero;                 // delta: biased so that delta[d.delta_off] is valid for the resident window
     int32_t *buf0, *buf1;
     uint16_t *bp;
     unsigned long long *digest;
@@ -239,7 +246,7 @@ __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, i
     const int nchunk = (RP + RC - 1) / RC;
     const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
     const bool has_delta = d.delta_off >= 0;
-    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
     const int dT = has_delta ? d.T : 0, dmask = has_delta ? -1 : 0;
     const uint32_t *gb = A.grp_begin + d.grp_first;
     unsigned long long dsum = 0;
@@ -363,7 +370,7 @@ struct FastArgs {
     const uint2 *slots;
     const uint32_t *in_edge;
     const int32_t *dead_cols;
-    const uint16_t *delta;
+    const uint16_t *delta, *delta_zero;
     int32_t *base0, *base1;                             // padded allocation starts of the two state buffers
     uint16_t *bp;                                       // fast-form levels always store narrow back-pointers
     unsigned long long *digest;
@@ -404,7 +411,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const int j2 = act ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
     const int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
     const bool has_delta = d.delta_off >= 0;
-    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
     const int dT = has_delta ? d.T : 0;
     const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
     const int evr = (int)((sl.y >> 20) & 0xFFu);                       // rank of this lane's in-edge inside its column's list
@@ -541,7 +548,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
         steps = 6;
     }
     const bool has_delta = d.delta_off >= 0;
-    const uint16_t *dm = A.delta + (has_delta ? d.delta_off : 0);      // delta[0..DELTA_PAD) is a zero slot
+    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
     const int dT = has_delta ? d.T : 0;
     const int du = (int)rr.y;
     if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
@@ -1298,7 +1305,25 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
 
     lap("descs + groups + slots");
     // memory budget, lattice chunking / segmentation
-    const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_entries * 2;
+    // score-delta windows (see DpState::dwin_t)
+    S.dtrans_host = dtrans;
+    S.dblk_first_host = dblk_first;
+    S.dblk_first_host.push_back(nblk);
+    S.dwin_t.assign(1, 0);
+    S.level_win.assign(L, -1);
+    {
+        int64_t acc = 0, max_win = 0;
+        for (size_t t = 0; t < dtrans.size(); ++t) {
+            const int64_t n = (int64_t)S.descs[dtrans[t]].T * S.descs[dtrans[t]].T;
+            if (acc > 0 && acc + n > S.delta_cap_entries) { S.dwin_t.push_back((int32_t)t); max_win = std::max(max_win, acc); acc = 0; }
+            acc += n;
+            S.level_win[dtrans[t]] = (int32_t)S.dwin_t.size() - 1;
+        }
+        max_win = std::max(max_win, acc);
+        S.dwin_t.push_back((int32_t)dtrans.size());
+        S.delta_buf_entries = DELTA_PAD + max_win;
+    }
+    const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_buf_entries * 2;
     size_t free_b = 0, total_b = 0;
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t pool_bytes;
@@ -1441,12 +1466,12 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     SweepArgs A;
     A.descs = descs; A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
     A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
-    A.delta = S.d_delta.as<uint16_t>();
+    A.delta = A.delta_zero = S.d_delta.as<uint16_t>();
     A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
     A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
     FastArgs F;
     F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.dead_cols = A.dead_cols;
-    F.delta = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
+    F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
     F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
     F.pad_bytes = (int)(4 * S.pad_front);
     F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
@@ -1457,11 +1482,26 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
 
     // Sweeps destination levels [lb, le).  bp_biased = lattice pointer minus the offset of level lb's first cell
     // (so the kernels keep using the global LevelDesc::bp_off), or nullptr for a value-only pass.
+    // (re)computes the score deltas of window w into d_delta and points the sweep arguments at it
+    const int n_win = (int)S.dwin_t.size() - 1;
+    auto load_window = [&](int w) {
+        const int t0 = S.dwin_t[w], t1 = S.dwin_t[w + 1];
+        if (t1 > t0) {
+            const int64_t b0 = S.dblk_first_host[t0], b1 = S.dblk_first_host[t1];
+            const int64_t base_off = S.descs[S.dtrans_host[t0]].delta_off;          // global entry offset of the window's first matrix
+            uint16_t *biased = S.d_delta.as<uint16_t>() + DELTA_PAD - base_off;
+            hipLaunchKernelGGL(dp_delta_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0, s, descs, S.d_dtrans.as<int32_t>(),
+                               S.d_dblk_first.as<int64_t>(), (int)S.dtrans_host.size(), S.d_in_edge.as<uint32_t>(), S.d_in_dst.as<int32_t>(), col,
+                               biased, b0);
+            A.delta = F.delta = biased;
+        }
+        S.cur_win = w;
+    };
     auto sweep_range = [&](int lb, int le, uint16_t *bp_biased) -> int {
         A.bp = bp_biased; F.bp = bp_biased;
         // runs of narrow levels may go to the one-XCD team kernel (one launch per run, optional); every other level
         // gets one whole-chip launch
-        const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed;
+        const bool team_ok = S.use_team && !S.want_digest && small_state && !team_failed && n_win == 1;
         S.schedule.clear();
         for (int l = lb; l < le;) {
             auto narrow = [&](int q) { const LevelDesc &d = S.descs[q]; return team_ok && d.fast_ok == 1 && (int64_t)d.k2 * d.nblocks <= S.team_max_tasks; };
@@ -1496,6 +1536,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
             }
             for (int l = seg.begin; l < seg.end; ++l) {
                 LevelDesc &d = S.descs[l];
+                if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
                 // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
                 // non-temporal ones that keep the once-written lattice out of the L2
                 d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
@@ -1599,12 +1640,8 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
 retry_forward:
     n_launch = 0; team_used = false; team_err = 0;
     DG_HIP(hipEventRecord(S.ev[0], s));
-    int ndt = 0;
-    for (int l = 1; l < S.L; ++l) if (S.descs[l].delta_off >= 0) ++ndt;
-    if (S.n_delta_blocks > 0)
-        hipLaunchKernelGGL(dp_delta_kernel, dim3((unsigned)S.n_delta_blocks), dim3(256), 0, s, descs, S.d_dtrans.as<int32_t>(),
-                           S.d_dblk_first.as<int64_t>(), ndt, S.d_in_edge.as<uint32_t>(), S.d_in_dst.as<int32_t>(), col,
-                           S.d_delta.as<uint16_t>());
+    S.cur_win = -1;
+    if (n_win == 1 && S.n_delta_blocks > 0) load_window(0);     // everything fits: computed once, up front (delta_ms)
     DG_HIP(hipEventRecord(S.ev[1], s));
     if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
     hipLaunchKernelGGL(dp_init_kernel, dim3(1), dim3(256 * ((S.RP + 255) / 256)), 0, s, state_ptr(0), S.RP);
@@ -1740,6 +1777,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "delta_cap_entries")) c->dp->delta_cap_entries = v > 0 ? v : (int64_t)4 << 30;   // takes effect at the next load
     else if (!strcmp(key, "rc_cap")) c->dp->rc_cap = v > 0 ? v : 16384;
     else if (!strcmp(key, "rc_t0_ns")) c->dp->rc_t0_ns = v;
     else if (!strcmp(key, "rc_tg_ps")) c->dp->rc_tg_ps = v;

@@ -164,6 +164,23 @@ def test_dp_segmented_lattice(gpu_ctx, seg_cells):
         gpu_ctx.dp_set_option("segment_cells", 0)
 
 
+@pytest.mark.parametrize("cap,seg", [(1, 0), (400, 0), (20000, 0), (400, 5000), (1, 1)])
+def test_dp_delta_windows(gpu_ctx, cap, seg):
+    """score-delta matrices that outgrow their budget are recomputed window by window right before the levels that read
+    them (chr22-scale panels: hundreds of GB otherwise) -- forced here with tiny budgets, alone and together with a
+    segmented lattice (whose second pass re-enters windows half way)"""
+    try:
+        gpu_ctx.dp_set_option("delta_cap_entries", cap)
+        gpu_ctx.dp_set_option("segment_cells", seg)
+        for seed, kw in [(31, dict(max_width=14, n_levels=300, R=6, p_colour=0.6)), (32, dict(max_width=45, n_levels=60, R=18, p_w1=0.5, p_colour=0.9)),
+                         (33, dict(n_levels=2, R=2)), (34, dict(max_width=8, n_levels=2000, R=3, p_colour=0.3)), (35, dict(R=33, max_width=25, n_levels=90, p_colour=0.1))]:
+            _dp_both(gpu_ctx, graphgen.random_levelized(8200 + seed, **kw))
+        _dp_both(gpu_ctx, capi.DpGraphArrays.load(os.path.join(HERE, "golden", "toy1_k5w3_R2.dpg")))
+    finally:
+        gpu_ctx.dp_set_option("delta_cap_entries", 0)
+        gpu_ctx.dp_set_option("segment_cells", 0)
+
+
 @pytest.mark.parametrize("chunk_cells", [1, 3000, 150000])
 def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
     """the resident back-pointer lattice is a pool of chunks mapped by a background thread while the sweep runs;
