@@ -11,7 +11,8 @@ t0 = time.time(); segs, links, walks, reads = synth.linear_panel(22, backbone_bp
 synth.write_gfa(f"{d}/c5.gfa", segs, links, walks); synth.write_fasta(f"{d}/c5.fa", reads)
 print(f"generated: {len(segs)} segments, {len(walks)} walks, {len(reads)} reads in {time.time()-t0:.1f}s", flush=True)
 env = dict(os.environ, DG_DEBUG="1")
-for rep in range(2):
+reps = int(os.environ.get("C5_REPS", "2"))
+for rep in range(reps):
     t0 = time.time()
     p = subprocess.run([f"{ROOT}/bin/DipGenie", "-t16", "-p2", f"-R{R}", "-g", f"{d}/c5.gfa", "-r", f"{d}/c5.fa", "-o", f"{d}/o{rep}.fa", "-J", f"{d}/o.json"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -19,7 +20,9 @@ for rep in range(2):
     for line in p.stderr.decode().split("\n"):
         if any(k in line for k in ("stage]", "lattice", "dg::dp", "Real time", "[E::")): print("  ", line)
     if p.returncode == 0: print("  ", {k: v for k, v in json.load(open(f"{d}/o.json")).items() if k != "stages"})
-print("outputs identical:", open(f"{d}/o0.fa").read() == open(f"{d}/o1.fa").read())
+if reps > 1: print("outputs identical:", open(f"{d}/o0.fa").read() == open(f"{d}/o1.fa").read())
+import resource
+print(f"peak RSS of the generator process: {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.1f} GB, children {resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6:.1f} GB")
 if len(sys.argv) > 4:      # also dump the levelized graph and keep a prefix window of it (kernel experiments)
     subprocess.run([f"{ROOT}/bin/DipGenie", "-t16", "-p2", f"-R{R}", "-g", f"{d}/c5.gfa", "-r", f"{d}/c5.fa", "-o", f"{d}/o2.fa", "-D", f"{d}/c5"],
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
