@@ -2,6 +2,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <climits>
 #include <cstdio>
@@ -132,24 +133,31 @@ void parse_L(Builder &b, std::vector<char *> &f) {          // gfa-io.cpp:279-36
     b.arcs.push_back({v, w, ov, ow});
 }
 
-void parse_W(Builder &b, std::vector<char *> &f) {          // gfa-io.cpp:367-432
+// W lines are the bulk of a pangenome GFA (one step per segment per haplotype) and independent of each other, so
+// they are kept as text while the file is read and parsed together afterwards, in parallel.  The reference resolves a
+// step against the segments seen SO FAR (gfa-io.cpp:367-432): segment ids are handed out in first-appearance order,
+// so "known when this line was read" is exactly id < n_seg_then.
+struct PendingWalk { std::string line; uint32_t n_seg_then; };
+
+void parse_W(const Builder &b, PendingWalk &pw, GfaWalk &t, std::string &warnings) {
+    std::vector<char *> f;
+    split_tabs(pw.line, f);
     if (f.size() < 7) return;
-    GfaWalk t;
     t.sample = f[1];
     t.hap = atoi(f[2]);
     const char *q = f[6];
     const char *end = q + strlen(q);
     const char *qq = q;
+    std::string name;
     for (const char *pp = q + 1; pp <= end; ++pp) {
         if (pp == end || *pp == '>' || *pp == '<') {
-            std::string name(qq + 1, pp - (qq + 1));
+            name.assign(qq + 1, pp - (qq + 1));
             auto it = b.name2id.find(name);
-            if (it != b.name2id.end()) t.v.push_back(it->second << 1 | (uint32_t)(*qq == '<'));
-            else fprintf(stderr, "WARNING: failed to find segment '%s'\n", name.c_str());
+            if (it != b.name2id.end() && it->second < pw.n_seg_then) t.v.push_back(it->second << 1 | (uint32_t)(*qq == '<'));
+            else warnings += "WARNING: failed to find segment '" + name + "'\n";
             qq = pp;
         }
     }
-    b.g.walks.push_back(std::move(t));
 }
 
 void walk_flip(GfaGraph &g) {                               // gfa-io.cpp:64-93
@@ -220,17 +228,30 @@ bool read_gfa_file(const std::string &path, GfaGraph &g, std::string &err) {
     LineReader lr(fp);
     std::string line;
     std::vector<char *> f;
+    std::vector<PendingWalk> pending;
     while (lr.next(line)) {
         if (line.size() < 3 || line[1] != '\t') continue;   // gfa-io.cpp:492
         char t = line[0];
         if (t != 'S' && t != 'L' && t != 'W') continue;
+        if (t == 'W') {
+            // (a W line with fewer than 7 fields adds no walk at all)
+            if (std::count(line.begin(), line.end(), '\t') >= 6) { pending.push_back({std::string(), g.n_seg()}); pending.back().line.swap(line); }
+            continue;
+        }
         split_tabs(line, f);
         if (t == 'S') parse_S(b, f);
-        else if (t == 'L') parse_L(b, f);
-        else parse_W(b, f);
+        else parse_L(b, f);
     }
     gzclose(fp);
-    lap("read + parse lines");
+    lap("read + parse S/L lines");
+    {
+        g.walks.resize(pending.size());
+        std::vector<std::string> warn(pending.size());
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t w = 0; w < (int64_t)pending.size(); ++w) parse_W(b, pending[w], g.walks[w], warn[w]);
+        for (auto &ws : warn) if (!ws.empty()) fputs(ws.c_str(), stderr);
+    }
+    lap("parse W lines");
     walk_flip(g);
     lap("walk_flip");
     finalize(b);
