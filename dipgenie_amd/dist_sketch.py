@@ -90,6 +90,8 @@ class ShardedSketch:
         """count[M] for the local shard, then all-reduce(sum) over ranks (RCCL)."""
         from . import capi
         counts = torch.zeros(dict_t.numel(), dtype=torch.int32, device=self.device)
+        if counts.is_cuda:
+            torch.cuda.current_stream(self.device).synchronize()   # the zero fill is on torch's stream, the join on the ctx stream
         capi._check(capi.lib.dg_sketch_count_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), c.data_ptr(),
                                                             h.numel(), counts.data_ptr()), "dg_sketch_count_dictionary_dev")
         self.ctx_sync()
