@@ -819,6 +819,7 @@ __global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, ever
 // (level, from, to, which) records; the host orders them by level.
 // ---------------------------------------------------------------------------------------------
 struct ChainState { int32_t i, j, r, value; };
+constexpr int32_t CHAIN_CORRUPT = INT32_MIN;            // ChainState::value after a hop left its level
 
 // Pulls the row records of a range of levels into the memory-side Infinity Cache right before the chain walk reads two
 // of them per level (they were last touched by the sweep, hundreds of GB of lattice writes ago).
@@ -836,12 +837,12 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
     int i, j, r, value, forced = 0;                                     // forced: bit 0 row, bit 1 column has one in-edge
     if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; i = 0; j = 0; r = R; }   // sink level, layout [i][r][j]: cell (0, R, 0)
     else { i = st->i; j = st->j; r = st->r; value = st->value; }
-    if (value != NEG_INF) {
-        for (int base = l_hi; base >= l_lo; base -= 64) {
+    if (value != NEG_INF && value != CHAIN_CORRUPT) {
+        for (int base = l_hi; base >= l_lo && value != CHAIN_CORRUPT; base -= 64) {
             const int my_l = base - lane;
             long long bo = 0;
-            int kk = 1, bb = 0;                                         // bb = first vertex of the level | wide << 31
-            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; bb = descs[my_l].b0 | (descs[my_l].bp_wide << 31); }
+            int kk = 1, bb = 0, kp = 1;                                 // bb = first vertex of the level | wide << 31; kp = source width
+            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; kp = descs[my_l].k; bb = descs[my_l].b0 | (descs[my_l].bp_wide << 31); }
             const int n = min(64, base - l_lo + 1);
             for (int t = 0; t < n; ++t) {
                 const int l = base - t;
@@ -881,6 +882,10 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
                 if (lane == 0) path[l] = hop;
                 i = (int)(hop & 0x7FFFu); j = (int)((hop >> 15) & 0x7FFFu);
                 r -= (int)((hop >> 30) & 1u) + (int)(hop >> 31);
+                // a hop that leaves the source level means the lattice is corrupt (a level nobody swept): stop before the next
+                // load goes wild -- the host reports DG_ERR_STATE instead of the GPU faulting
+                const int kprev = __builtin_amdgcn_readlane(kp, t);
+                if ((i >= kprev) | (j >= kprev) | (r < 0)) { value = CHAIN_CORRUPT; i = j = 0; r = 0; break; }
             }
         }
     }
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(1024) void dp_trace_finish_kernel(const LevelDesc *
     if (threadIdx.x == 0) { s_shet = 0; s_ne = 0; }
     __syncthreads();
     const int value = st->value;
-    if (value != NEG_INF) {
+    if (value != NEG_INF && value != CHAIN_CORRUPT) {
         int shet = 0;
         for (int l = 1 + (int)threadIdx.x; l < L; l += (int)blockDim.x) {
             const uint32_t b = path[l];
@@ -1708,6 +1713,7 @@ retry_forward:
     DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
     S.timing.n_forward_launches = n_launch;
+    if (to.value == CHAIN_CORRUPT) { set_error("back-pointer lattice is corrupt: the chain walk left its level (a level was not swept?)"); return DG_ERR_STATE; }
     if (to.overflow || to.n_e > S.cap) { set_error("traceback edge list overflow (%d > %d)", to.n_e, S.cap); return DG_ERR_STATE; }
     res->value = to.value; res->s_het = to.s_het;
     res->cells = S.cells; res->relaxations = S.relaxations;
