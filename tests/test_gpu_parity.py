@@ -231,6 +231,33 @@ def test_dp_giant_indegree_uses_generic_path(gpu_ctx, k):
     _dp_both(gpu_ctx, g)
 
 
+def test_dp_contexts_are_independent(gpu_ctx):
+    """"a ctx is not thread-safe, different ctxs are independent" (include/dipgenie_hip.h): three contexts on one GPU,
+    one host thread each, different graphs in flight at the same time -- the cohort mode bench.py measures"""
+    import threading
+    graphs = [graphgen.random_levelized(8300 + q, max_width=20 + 5 * q, n_levels=400 + 100 * q, R=6 + 6 * q, p_colour=0.4) for q in range(3)]
+    refs = [orc.dp_solve(g) for g in graphs]
+    ctxs = [capi.Context(0) for _ in graphs]
+    got, errs = [None] * 3, []
+
+    def work(q):
+        try:
+            for _ in range(4):
+                got[q] = ctxs[q].dp_solve(graphs[q])
+        except Exception as e:                                  # noqa: BLE001 - reported below
+            errs.append((q, repr(e)))
+    th = [threading.Thread(target=work, args=(q,)) for q in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in ctxs:
+        c.close()
+    assert not errs, errs
+    for q in range(3):
+        assert (got[q].value, got[q].s_het, got[q].p1, got[q].p2) == (refs[q]["value"], refs[q]["s_het"], refs[q]["p1"], refs[q]["p2"]), q
+
+
 def test_dp_unreachable_sink(gpu_ctx):
     # every path to the sink needs 2 recombinations but R = 1: value stays NEG_INF, edge lists empty
     lo = np.array([0, 1, 2, 3], np.int32)
