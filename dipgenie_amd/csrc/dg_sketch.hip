@@ -36,7 +36,7 @@ struct Tile {
 };
 
 struct SketchState {
-    DevBuf d_bases, d_tiles, d_tile_cnt, d_tile_base, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
+    DevBuf d_bases, d_tiles, d_tile_cnt, d_tile_base, d_tile_sparse, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
     dg_sketch_timing timing;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -98,7 +98,9 @@ __device__ __forceinline__ int cmp_canon(const uint8_t *s, int k, int p, int op,
 }
 
 // ------------------------------------------------------------------ tile kernel
-// MODE 0: count emissions per tile; MODE 1: write hashes (+ aux: seq_id for reads, position for haplotypes)
+// MODE 0: count emissions per tile; MODE 1: write hashes (+ aux: seq_id for reads, position for haplotypes) at tile_base;
+// MODE 2 (the one in use): both in one pass -- tile_base holds SPARSE offsets (prefix of windows per tile, an upper bound
+// of the emissions), a compaction kernel closes the gaps afterwards.  Two passes meant hashing everything twice.
 template <int MODE, bool AUX_IS_POS>
 __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict__ bases, const Tile *__restrict__ tiles,
                                                           int64_t n_tiles, int k, int w, int64_t *__restrict__ tile_cnt,
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     if (!active) return;
 
     // emission (solver.cpp:329-335 / 401-407)
-    int64_t wbase = MODE == 1 ? tile_base[tile_id] : 0;
+    int64_t wbase = MODE >= 1 ? tile_base[tile_id] : 0;
     int64_t total = 0;
     for (int round = 0; round * 64 < T.nwin; ++round) {
         const int wi = round * 64 + lane;                // tile-local window (without the prev offset)
@@ -193,14 +195,25 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             }
         }
         const unsigned long long m = __ballot(emit);
-        if (MODE == 1 && emit) {
+        if (MODE >= 1 && emit) {
             const int64_t slot = wbase + total + __popcll(m & ((1ULL << lane) - 1ULL));
             out_hash[slot] = H;
             out_aux[slot] = AUX_IS_POS ? (int64_t)(km0 + p) : (int64_t)T.seq_id;
         }
         total += __popcll(m);
     }
-    if (MODE == 0 && lane == 0) tile_cnt[tile_id] = total;
+    if (MODE != 1 && lane == 0) tile_cnt[tile_id] = total;
+}
+
+// closes the gaps of the single-pass output: one wave per tile copies its cnt entries from the sparse to the dense offset
+__global__ __launch_bounds__(256) void compact_tiles_kernel(const int64_t *__restrict__ sparse_base, const int64_t *__restrict__ dense_base,
+                                                            const int64_t *__restrict__ cnt, int64_t n_tiles, const uint64_t *__restrict__ sh,
+                                                            const int64_t *__restrict__ sa, uint64_t *__restrict__ dh, int64_t *__restrict__ da) {
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t sb = sparse_base[tile], db = dense_base[tile], n = cnt[tile];
+    for (int64_t t = lane; t < n; t += 64) { dh[db + t] = sh[sb + t]; da[db + t] = sa[sb + t]; }
 }
 
 __global__ void pair_flag_kernel(const uint64_t *__restrict__ hash, const int64_t *__restrict__ seq, int64_t n, int32_t *__restrict__ flag) {
@@ -248,7 +261,7 @@ static void make_tiles(const int64_t *off, int64_t n_seq, int k, int w, std::vec
     }
 }
 
-// Runs the two-pass tile kernel over device-resident bases. On return d_hash/d_aux hold n_emit entries.
+// Runs the tile kernel (+ compaction) over device-resident bases. On return d_hash/d_aux hold n_emit entries.
 template <bool AUX_IS_POS>
 static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &tiles, int k, int w, int64_t *n_emit) {
     SketchState &S = state(c);
@@ -260,10 +273,18 @@ static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &
     DG_HIP(hipMemcpyAsync(S.d_tiles.p, tiles.data(), sizeof(Tile) * nt, hipMemcpyHostToDevice, s));
     if (int rc = S.d_tile_cnt.ensure(8 * (nt + 1))) return rc;
     if (int rc = S.d_tile_base.ensure(8 * (nt + 1))) return rc;
+    if (int rc = S.d_tile_sparse.ensure(8 * (nt + 1))) return rc;
+    // sparse offsets: a tile emits at most one minimizer per window
+    std::vector<int64_t> sparse((size_t)nt + 1, 0);
+    for (int64_t t = 0; t < nt; ++t) sparse[t + 1] = sparse[t] + tiles[t].nwin;
+    const int64_t n_win = sparse[nt];
+    DG_HIP(hipMemcpyAsync(S.d_tile_sparse.p, sparse.data(), 8 * (size_t)(nt + 1), hipMemcpyHostToDevice, s));
+    if (int rc = S.d_hash2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;     // sparse output (dead before the sort reuses them)
+    if (int rc = S.d_aux2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;
     const size_t lpw = lds_per_wave(k, w);
     const unsigned grid = (unsigned)((nt + 3) / 4);
-    hipLaunchKernelGGL((sketch_tile_kernel<0, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
-                       S.d_tile_cnt.as<int64_t>(), (const int64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr, (int)lpw);
+    hipLaunchKernelGGL((sketch_tile_kernel<2, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       S.d_tile_cnt.as<int64_t>(), S.d_tile_sparse.as<int64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), (int)lpw);
     // exclusive scan of counts (as int64) -> tile_base; total at [nt]
     DG_HIP(hipMemsetAsync((char *)S.d_tile_cnt.p + 8 * nt, 0, 8, s));
     size_t tb = 0;
@@ -273,13 +294,13 @@ static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &
     DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
     int64_t total = 0;
     DG_HIP(hipMemcpyAsync(&total, S.d_tile_base.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, s));
-    DG_HIP(hipStreamSynchronize(s));
+    DG_HIP(hipStreamSynchronize(s));                                 // (also keeps `sparse` alive long enough)
     *n_emit = total;
     if (total == 0) return DG_OK;
     if (int rc = S.d_hash.ensure(8 * total)) return rc;
     if (int rc = S.d_aux.ensure(8 * total)) return rc;
-    hipLaunchKernelGGL((sketch_tile_kernel<1, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
-                       (int64_t *)nullptr, S.d_tile_base.as<int64_t>(), S.d_hash.as<uint64_t>(), S.d_aux.as<int64_t>(), (int)lpw);
+    hipLaunchKernelGGL(compact_tiles_kernel, dim3(grid), dim3(256), 0, s, S.d_tile_sparse.as<int64_t>(), S.d_tile_base.as<int64_t>(), S.d_tile_cnt.as<int64_t>(),
+                       nt, S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), S.d_hash.as<uint64_t>(), S.d_aux.as<int64_t>());
     DG_HIP(hipGetLastError());
     return DG_OK;
 }
