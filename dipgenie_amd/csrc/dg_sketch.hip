@@ -26,6 +26,8 @@
 namespace dgi {
 
 constexpr int TW = 128;                 // windows per tile (2 per lane)
+constexpr int PLANE_WORDS = 12;         // 64-bit words per base bit plane: (TW + 255 + 255) / 64 + 2
+#define PLANE_OFF(k, w) ((8 * (TW + (w)) + 4 * (TW + 1) + (TW + (w)) + (TW + (w) + (k)) + 7) & ~7)
 
 struct Tile {
     int64_t seq_start;                  // offset of the sequence in the bases buffer
@@ -97,6 +99,28 @@ __device__ __forceinline__ int cmp_canon(const uint8_t *s, int k, int p, int op,
     return 0;
 }
 
+// spreads the low 32 bits of x to the even bit positions
+__device__ __forceinline__ uint64_t spread32(uint64_t x) {
+    x &= 0xFFFFFFFFULL;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+// bits [q, q + n) of the bit string m[0] | m[1] << 64 | ... (n <= 32)
+__device__ __forceinline__ uint32_t bits_at(const uint64_t *m, int q, int n) {
+    const int wd = q >> 6, sh = q & 63;
+    uint64_t v = m[wd] >> sh;
+    if (sh) v |= m[wd + 1] << (64 - sh);
+    return (uint32_t)(v & ((n >= 32) ? 0xFFFFFFFFULL : ((1ULL << n) - 1ULL)));
+}
+// byte t of a k-mer given as 2-bit code (first base most significant)
+__device__ __forceinline__ uint8_t code_byte(uint64_t code, int k, int t) {
+    return (uint8_t)(0x54474341u >> (8 * (int)((code >> (2 * (k - 1 - t))) & 3ULL)));   // "ACGT"
+}
+
 // ------------------------------------------------------------------ tile kernel
 // MODE 0: count emissions per tile; MODE 1: write hashes (+ aux: seq_id for reads, position for haplotypes) at tile_base;
 // MODE 2 (the one in use): both in one pass -- tile_base holds SPARSE offsets (prefix of windows per tile, an upper bound
@@ -127,20 +151,29 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     __syncthreads();
 
     // canonical 2-bit code / orientation per k-mer (first base most significant: integer order ==
-    // lexicographic order; A<C<G<T matches ASCII)
+    // lexicographic order; A<C<G<T matches ASCII).  The bases are turned into three bit planes with wave ballots (low
+    // code bit, high code bit, "not ACGT"), so a k-mer's forward and reverse-complement codes are two bit-field
+    // extractions + an interleave instead of a k-step loop over LDS bytes.
+    uint64_t *plane = (uint64_t *)(base + PLANE_OFF(k, w));           // [3][PLANE_WORDS]: low code bit, high code bit, not-ACGT
+    if (lane < 3 * PLANE_WORDS) plane[lane] = 0;
+    __syncthreads();
+    for (int rd = 0; rd * 64 < nb; ++rd) {
+        const int t = rd * 64 + lane;
+        const int cf = t < nb ? code2(sq[t]) : -1;
+        const unsigned long long mlo = __ballot(cf >= 0 && (cf & 1)), mhi = __ballot(cf >= 0 && (cf & 2)), minv = __ballot(t < nb && cf < 0);
+        if (lane == 0) { plane[rd] = mlo; plane[PLANE_WORDS + rd] = mhi; plane[2 * PLANE_WORDS + rd] = minv; }
+    }
+    __syncthreads();
     for (int q = lane; q < nkm; q += 64) {
-        uint64_t f = 0, r = 0;
-        bool valid = (k <= 32);
-        if (valid) {
-            for (int t = 0; t < k; ++t) {
-                const int cf = code2(sq[q + t]);
-                if (cf < 0) { valid = false; break; }
-                f = (f << 2) | (uint64_t)cf;
-                r |= (uint64_t)(3 - cf) << (2 * t);     // reverse complement, same significance convention
-            }
-        }
+        bool valid = (k <= 32) && bits_at(plane + 2 * PLANE_WORDS, q, k) == 0;
         int o;
         if (valid) {
+            const uint32_t lo = bits_at(plane, q, k), hi = bits_at(plane + PLANE_WORDS, q, k);   // bit t = base q + t
+            const uint32_t msk = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+            // forward: base 0 most significant -> reverse the k-bit fields; reverse complement: base t at digit t, complemented
+            const uint32_t rlo = __brev(lo) >> (32 - k), rhi = __brev(hi) >> (32 - k);
+            const uint64_t f = spread32(rlo) | (spread32(rhi) << 1);
+            const uint64_t r = spread32(~lo & msk) | (spread32(~hi & msk) << 1);
             o = r < f ? 1 : 0;
             code[q] = o ? r : f;
         } else {
@@ -180,7 +213,10 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         if (wi < T.nwin) {
             p = wpos[wi + has_prev];
             const int op = (info[p] >> 1) & 1;
-            auto bp = [&](int t) -> uint8_t { return canon_byte(sq, p, k, op, t); };
+            const bool vp = info[p] & 1;
+            const uint64_t cp = code[p];
+            // (ACGT-only k-mers are hashed from their code: no LDS byte gathers)
+            auto bp = [&](int t) -> uint8_t { return vp ? code_byte(cp, k, t) : canon_byte(sq, p, k, op, t); };
             if (T.win0 + wi == 0) {                      // first window of the sequence: prev_hash = UINT64_MAX
                 H = murmur3_fold(bp, k);
                 emit = H != UINT64_MAX;
@@ -188,7 +224,9 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
                 const int q = wpos[wi + has_prev - 1];
                 if (q != p) {
                     const int oq = (info[q] >> 1) & 1;
-                    auto bq = [&](int t) -> uint8_t { return canon_byte(sq, q, k, oq, t); };
+                    const bool vq = info[q] & 1;
+                    const uint64_t cq = code[q];
+                    auto bq = [&](int t) -> uint8_t { return vq ? code_byte(cq, k, t) : canon_byte(sq, q, k, oq, t); };
                     H = murmur3_fold(bp, k);
                     emit = H != murmur3_fold(bq, k);
                 }
@@ -247,7 +285,7 @@ static SketchState &state(dg_ctx *c) {
 }
 
 static size_t lds_per_wave(int k, int w) {
-    size_t b = 8 * (size_t)(TW + w) + 4 * (size_t)(TW + 1) + (size_t)(TW + w) + (size_t)(TW + w + k);
+    size_t b = (size_t)PLANE_OFF(k, w) + 8 * 3 * (size_t)PLANE_WORDS;
     return (b + 15) & ~(size_t)15;
 }
 
