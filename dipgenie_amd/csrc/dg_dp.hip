@@ -67,6 +67,7 @@ struct DpState {
     int64_t segment_cells = 0;                          // option: force segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // option: threads used by dg_dp_load_graph's table construction
     int64_t bp_nt_min_cells = 16384;                    // option: levels with at least this many cells stream their back-pointers non-temporally
+    int64_t chain_spec = 1;                             // option: speculative chain walk (0: the plain one)
     int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
@@ -892,6 +893,131 @@ __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__r
     if (lane == 0) { st->i = i; st->j = j; st->r = r; st->value = value; }
 }
 
+// Speculative form of the chain walk (the default).  A step of the walk above costs one HBM round trip because the next
+// cell's address needs this level's back-pointer.  But the candidates are few: with at most two in-edges into the row
+// and into the column (97 % of the vertices) the predecessor is one of four cells, all known as soon as the two row
+// records are in.  Lanes 0..3 (mirrored by the other lanes) therefore load the back-pointer AND the row records of
+// "their" candidate one level ahead; when this level's back-pointer arrives it only selects the lane whose loads are
+// already in flight, so two levels' HBM round trips overlap.  A rank above 1 or a wide level resolves the predecessor
+// with extra loads and re-issues exact loads for it.
+// Shape of the code (it matters: the compiler derives its s_waitcnt from it): every path through a step ends with the
+// three loads (row record, column record, back-pointer word) of the next level as the most recent memory operations, and
+// a step consumes only what the previous step issued; the step is instantiated twice with the two register sets swapped,
+// because copying a register that still has a load in flight would wait for that load.
+struct ChainWalk {
+    int i, j, r, value, csel;
+};
+struct ChainRegs { uint4 row, col; uint32_t b; };
+struct ChainDesc { long long bo; int k2, bw, kp; };    // bp offset, width, first vertex | wide << 31, source width
+
+// loads of one cell (level descriptor bo/k2/bw): row records + the aligned 32-bit word that holds its back-pointer
+__device__ __forceinline__ void chain_issue(ChainRegs &Y, const uint16_t *__restrict__ bp, const uint4 *__restrict__ rowrec, long long bo, int k2, int bw,
+                                            int RP, int ci, int cj, int cr) {
+    const int b0 = bw & 0x7FFFFFFF;
+    const long long unit = bo + (((long long)ci * RP + cr) * k2 + cj) * (bw < 0 ? 2 : 1);
+    Y.row = rowrec[b0 + ci];
+    Y.col = rowrec[b0 + cj];
+    Y.b = *(const uint32_t *)(bp + (unit & ~1LL));
+}
+
+__device__ __forceinline__ void chain_spec_step(ChainWalk &W, int l, int l_lo, int RP, const ChainDesc &D, const ChainDesc &N,
+                                                const uint16_t *__restrict__ bp, const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
+                                                uint32_t &hops, int slot, int lane, ChainRegs &X, ChainRegs &Y) {
+    const int ca = lane & 1, cb = (lane >> 1) & 1;                      // this lane's candidate: rank ca of the row, cb of the column
+    const long long bo_l = D.bo, nbo = N.bo;
+    const int k2 = D.k2, bw = D.bw, kprev = D.kp, nk2 = N.k2, nbw = N.bw;
+    const int cs = W.csel;
+    const uint32_t rix = (uint32_t)__builtin_amdgcn_readlane((int)X.row.x, cs), riy = (uint32_t)__builtin_amdgcn_readlane((int)X.row.y, cs);
+    const uint32_t riz = (uint32_t)__builtin_amdgcn_readlane((int)X.row.z, cs), riw = (uint32_t)__builtin_amdgcn_readlane((int)X.row.w, cs);
+    const uint32_t rjx = (uint32_t)__builtin_amdgcn_readlane((int)X.col.x, cs), rjy = (uint32_t)__builtin_amdgcn_readlane((int)X.col.y, cs);
+    const uint32_t rjz = (uint32_t)__builtin_amdgcn_readlane((int)X.col.z, cs), rjw = (uint32_t)__builtin_amdgcn_readlane((int)X.col.w, cs);
+    // one level ahead: the four candidate cells of level l - 1; a lane without a valid candidate re-reads this level's cell
+    const bool have_next = l - 1 >= l_lo;
+    const uint32_t wa = ca ? riw : riz, wb = cb ? rjw : rjz;
+    const int ci = (int)(wa & 0x7FFFu), cj = (int)(wb & 0x7FFFu), cr = W.r - (int)(wa >> 31) - (int)(wb >> 31);
+    const bool ok = have_next & ((uint32_t)ca < riy) & ((uint32_t)cb < rjy) & (cr >= 0) & (ci < kprev) & (cj < kprev);
+    chain_issue(Y, bp, rowrec, ok ? nbo : bo_l, ok ? nk2 : k2, ok ? nbw : bw, RP, ok ? ci : W.i, ok ? cj : W.j, ok ? cr : W.r);
+    // this level's back-pointer word (issued one step ago)
+    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)X.b, cs);
+    uint32_t hop;
+    bool exact_next = false;                                            // the predecessor is not among the candidates in flight
+    if (bw < 0) {                                                       // wide level: the word is the hop
+        hop = word;
+        exact_next = true;
+    } else {
+        const long long unit = bo_l + ((long long)W.i * RP + W.r) * k2 + W.j;
+        const uint32_t bv = (unit & 1) ? (word >> 16) : (word & 0xFFFFu);
+        const uint32_t eu = bv >> 8, ev = bv & 0xFFu;
+        if (eu >= riy || ev >= rjy) { W.value = CHAIN_CORRUPT; W.i = W.j = 0; W.r = 0; return; }   // (0xFFFF = unreachable lands here too)
+        const uint32_t pu = eu == 0 ? riz : (eu == 1 ? riw : in_edge[rix + eu]);
+        const uint32_t pv = ev == 0 ? rjz : (ev == 1 ? rjw : in_edge[rjx + ev]);
+        hop = (pu & 0x7FFFu) | ((pv & 0x7FFFu) << 15) | ((pu >> 31) << 30) | ((pv >> 31) << 31);
+        exact_next = (eu > 1) | (ev > 1);
+        W.csel = (int)((eu & 1u) | ((ev & 1u) << 1));
+    }
+    hops = lane == slot ? hop : hops;                                   // lane t keeps the hop of the batch's t-th level: one store per batch,
+    W.i = (int)(hop & 0x7FFFu); W.j = (int)((hop >> 15) & 0x7FFFu);     // none inside the walk (stores share the loads' counter)
+    W.r -= (int)((hop >> 30) & 1u) + (int)(hop >> 31);
+    // a hop that leaves the source level means the lattice is corrupt (a level nobody swept): stop before the next
+    // load goes wild -- the host reports DG_ERR_STATE instead of the GPU faulting
+    if ((W.i >= kprev) | (W.j >= kprev) | (W.r < 0)) { W.value = CHAIN_CORRUPT; W.i = W.j = 0; W.r = 0; return; }
+    if (have_next && (exact_next || nbw < 0)) {                         // rare: exact loads of the predecessor replace the candidates
+        chain_issue(Y, bp, rowrec, nbo, nk2, nbw, RP, W.i, W.j, W.r);
+        W.csel = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
+                                                                 const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
+                                                                 const int32_t *__restrict__ final_val /* non-null on the first call */,
+                                                                 const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
+                                                                 uint32_t *__restrict__ path, ChainState *st) {
+    const int lane = threadIdx.x & 63;
+    ChainWalk W;
+    W.csel = 0;
+    if (final_val) { W.value = final_val[(int64_t)R * descs[l_hi].k2]; W.i = 0; W.j = 0; W.r = R; }   // sink level, layout [i][r][j]: cell (0, R, 0)
+    else { W.i = st->i; W.j = st->j; W.r = st->r; W.value = st->value; }
+    if (W.value != NEG_INF && W.value != CHAIN_CORRUPT) {
+        ChainRegs A, B;
+        bool first = true;
+        for (int base = l_hi; base >= l_lo && W.value != CHAIN_CORRUPT; base -= 56) {
+            const int my_l = base - lane;                               // 64 descriptors, 56 levels (a multiple of 8) per batch
+            long long bo = 0;
+            int kk = 1, bb = 0, kp = 1;                                 // bb = first vertex of the level | wide << 31; kp = source width
+            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; kp = descs[my_l].k; bb = descs[my_l].b0 | (descs[my_l].bp_wide << 31); }
+            asm volatile("" ::"v"(bo), "v"(kk), "v"(bb), "v"(kp));      // descriptors complete before the walk (no wait inside the loop)
+            const int n = min(56, base - l_lo + 1);
+            uint32_t hops = 0;
+#define DG_DESC(T) ChainDesc{((long long)__builtin_amdgcn_readlane((int)(bo >> 32), (T)) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)bo, (T)), \
+                            __builtin_amdgcn_readlane(kk, (T)), __builtin_amdgcn_readlane(bb, (T)), __builtin_amdgcn_readlane(kp, (T))}
+            ChainDesc D0 = DG_DESC(0), D1;                              // descriptor of the level at hand / one level ahead, rotated like the registers
+            if (first) {                                                // prologue: exact loads of the starting cell
+                chain_issue(A, bp, rowrec, D0.bo, D0.k2, D0.bw, RP, W.i, W.j, W.r);
+                first = false;
+            }
+            // unrolled by hand (8 steps per trip): the loop's back edge copies the registers of the loads in flight, and so
+            // waits for them -- one un-overlapped step per trip
+#define DG_CHAIN_STOP(T) (W.value == CHAIN_CORRUPT || (T) >= n)
+#define DG_CHAIN_STEP(T, X, Y, DC, DN) DN = DG_DESC((T) + 1); chain_spec_step(W, base - (T), l_lo, RP, DC, DN, bp, rowrec, in_edge, hops, (T), lane, X, Y)
+            for (int t = 0; t < n; t += 8) {
+                DG_CHAIN_STEP(t, A, B, D0, D1);     if (DG_CHAIN_STOP(t + 1)) break;
+                DG_CHAIN_STEP(t + 1, B, A, D1, D0); if (DG_CHAIN_STOP(t + 2)) break;
+                DG_CHAIN_STEP(t + 2, A, B, D0, D1); if (DG_CHAIN_STOP(t + 3)) break;
+                DG_CHAIN_STEP(t + 3, B, A, D1, D0); if (DG_CHAIN_STOP(t + 4)) break;
+                DG_CHAIN_STEP(t + 4, A, B, D0, D1); if (DG_CHAIN_STOP(t + 5)) break;
+                DG_CHAIN_STEP(t + 5, B, A, D1, D0); if (DG_CHAIN_STOP(t + 6)) break;
+                DG_CHAIN_STEP(t + 6, A, B, D0, D1); if (DG_CHAIN_STOP(t + 7)) break;
+                DG_CHAIN_STEP(t + 7, B, A, D1, D0); if (DG_CHAIN_STOP(t + 8)) break;
+            }
+#undef DG_CHAIN_STOP
+#undef DG_CHAIN_STEP
+#undef DG_DESC
+            if (lane < n && W.value != CHAIN_CORRUPT) path[base - lane] = hops;
+        }
+    }
+    if (lane == 0) { st->i = W.i; st->j = W.j; st->r = W.r; st->value = W.value; }
+}
+
 __global__ __launch_bounds__(1024) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
                                                                ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
                                                                const ChainState *st, TraceOut *out) {
@@ -1636,9 +1762,13 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         for (int ch = c1 - 1; ch >= c0; --ch) {
             const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
             warm_rows(lb, le);
-            hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch - c0],
-                               from_sink && ch == c1 - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(),
-                               S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+            const int32_t *fv = from_sink && ch == c1 - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr;
+            if (S.chain_spec)
+                hipLaunchKernelGGL(dp_trace_chain_spec_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch - c0], fv, S.d_rowrec.as<uint4>(),
+                                   S.d_in_edge.as<uint32_t>(), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+            else
+                hipLaunchKernelGGL(dp_trace_chain_kernel, dim3(1), dim3(64), 0, s, descs, le - 1, lb, S.RP, S.R, biased[ch - c0], fv, S.d_rowrec.as<uint4>(),
+                                   S.d_in_edge.as<uint32_t>(), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
         }
         return DG_OK;
     };
@@ -1783,6 +1913,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "chain_spec")) c->dp->chain_spec = v;
     else if (!strcmp(key, "delta_cap_entries")) c->dp->delta_cap_entries = v > 0 ? v : (int64_t)4 << 30;   // takes effect at the next load
     else if (!strcmp(key, "rc_cap")) c->dp->rc_cap = v > 0 ? v : 16384;
     else if (!strcmp(key, "rc_t0_ns")) c->dp->rc_t0_ns = v;
