@@ -6,7 +6,7 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdipgenie_hip.so")
+LIB_PATH = os.environ.get("DG_LIB") or os.path.join(_HERE, "csrc", "libdipgenie_hip.so")   # DG_LIB: A/B runs of two builds (tools/)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

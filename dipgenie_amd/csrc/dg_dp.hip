@@ -379,6 +379,11 @@ struct FastArgs {
     uint32_t buf_bytes;                                 // size of one padded state buffer
 };
 
+// neighbour exchange by one lane as DPP wave shifts (a few cycles) instead of ds_bpermute (an LDS crossbar round trip):
+// most column groups need exactly one step of the segmented max (columns with at most two in-edges)
+__device__ __forceinline__ int lane_down1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1: lane i <- lane i + 1 */, 0xF, 0xF, false); }
+__device__ __forceinline__ int lane_up1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1: lane i <- lane i - 1 */, 0xF, 0xF, false); }
+
 template <int RC>
 __device__ __forceinline__ void relax_select(const int (&vals)[RC], int dl, uint32_t ord, int r0, int w, int RP,
                                              int (&bval)[RC], uint32_t (&bord)[RC]) {
@@ -453,7 +458,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         // heavy rows (recombination fan-in): U in-edges per step -- all their loads (U deltas + U*RC values) go out
         // back to back, then the selects run; (value, ord) max is associative and commutative, so the order inside
         // a step is irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
-        constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : (RC >= 2 ? 8 : 16));
+        constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
         for (int t = 0; t < du; t += U) {
             uint32_t pu[U];
 #pragma unroll
@@ -482,7 +487,19 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     }
     if (PROF) q2 = __builtin_amdgcn_s_memtime();
     // segmented max over lanes with equal destination column (lanes of a column are adjacent)
-    for (int st = 0, sh = 1; st < steps; ++st, sh <<= 1) {
+    if (steps > 0) {                                                    // first step: distance 1, DPP
+        const int oj2 = lane_down1(j2);
+        const bool same = (lane + 1 < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int ov = lane_down1(bval[q]);
+            const uint32_t oo = (uint32_t)lane_down1((int)bord[q]);
+            const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+            bval[q] = take ? ov : bval[q];
+            bord[q] = take ? oo : bord[q];
+        }
+    }
+    for (int st = 1, sh = 2; st < steps; ++st, sh <<= 1) {
         const int oj2 = __shfl_down(j2, sh);
         const bool same = (lane + sh < 64) & (oj2 == j2);
 #pragma unroll
@@ -494,7 +511,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             bord[q] = take ? oo : bord[q];
         }
     }
-    const int pj2 = __shfl_up(j2, 1);
+    const int pj2 = lane_up1(j2);
     const bool head = act & ((lane == 0) | (pj2 != j2));
     unsigned long long dsum = 0;
     if (PROF) q3 = __builtin_amdgcn_s_memtime();
@@ -503,7 +520,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         for (int q = 0; q < RC; ++q) {
             const int r2 = r0 + q;
             if (r2 < RP) {
-                const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                const int idx = (i2 * RP + r2) * d.k2 + j2;            // fast form: a state buffer is < 2 GB, 32-bit indices
                 nxt[idx] = bval[q];
                 if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
                 if (DIGEST && bval[q] != NEG_INF) {
@@ -595,7 +612,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             // with readlane; U in-edges per step -- all their loads (U deltas + U*RC values) go out back to back, then
             // the selects run; (value, ord) max is associative and commutative, so the order inside a step is
             // irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
-            constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : (RC >= 2 ? 8 : 16));
+            constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
             for (int c0 = 0; c0 < du; c0 += 64) {
                 const int dc = min(64, du - c0);
                 uint32_t mypu = 0;
@@ -630,7 +647,19 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
     }
     if (PROF) q2 = __builtin_amdgcn_s_memtime();
     // segmented max over lanes with equal destination column (lanes of a column are adjacent)
-    for (int st = 0, sh = 1; st < steps; ++st, sh <<= 1) {
+    if (steps > 0) {                                                    // first step: distance 1, DPP
+        const int oj2 = lane_down1(j2);
+        const bool same = (lane + 1 < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int ov = lane_down1(bval[q]);
+            const uint32_t oo = (uint32_t)lane_down1((int)bord[q]);
+            const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+            bval[q] = take ? ov : bval[q];
+            bord[q] = take ? oo : bord[q];
+        }
+    }
+    for (int st = 1, sh = 2; st < steps; ++st, sh <<= 1) {
         const int oj2 = __shfl_down(j2, sh);
         const bool same = (lane + sh < 64) & (oj2 == j2);
 #pragma unroll
@@ -642,7 +671,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             bord[q] = take ? oo : bord[q];
         }
     }
-    const int pj2 = __shfl_up(j2, 1);
+    const int pj2 = lane_up1(j2);
     const bool head = act & ((lane == 0) | (pj2 != j2));
     unsigned long long dsum = 0;
     if (PROF) q3 = __builtin_amdgcn_s_memtime();
@@ -651,7 +680,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
         for (int q = 0; q < RC; ++q) {
             const int r2 = r0 + q;
             if (r2 < RP) {
-                const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                const int idx = (i2 * RP + r2) * d.k2 + j2;            // fast form: a state buffer is < 2 GB, 32-bit indices
                 nxt[idx] = bval[q];
                 if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
                 if (DIGEST && bval[q] != NEG_INF) {
@@ -679,14 +708,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
     return __builtin_amdgcn_make_buffer_rsrc((void *)padded_base, 0, bytes, 0x00020000);
 }
 
-// per-level launch of the fast form: grid = (ceil(ngroups/4), k2 * nchunk), one task per wave
+// per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2), one task per wave (a 3-D grid: splitting a
+// combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
 template <int RC, bool DIGEST, bool GENERAL>
 __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl) {
     const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
-    const int nchunk = (A.RP + RC - 1) / RC;
-    const int i2 = nchunk == 1 ? (int)blockIdx.y : (int)blockIdx.y / nchunk;
-    const int r0 = nchunk == 1 ? 0 : ((int)blockIdx.y % nchunk) * RC;
+    const int i2 = (int)blockIdx.z, r0 = (int)blockIdx.y * RC;         // chunks of a row are neighbours in dispatch order: they share its delta row
     const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
     if (GENERAL) sweep_task_general<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
@@ -1671,7 +1699,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                 // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
                 // non-temporal ones that keep the once-written lattice out of the L2
                 d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
-                if (d.fast_ok && small_state && (int64_t)d.k2 * S.RP <= 65535 && S.use_fast) {
+                if (d.fast_ok && small_state && S.RP <= 65535 && S.use_fast) {
                     // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
                     // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
                     const int64_t base = (int64_t)d.k2 * d.nblocks;
@@ -1698,7 +1726,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                     }
                     const int nch = (S.RP + rc - 1) / rc;
                     const int wpb = (int)S.waves_per_block;               // waves (= slot blocks) per workgroup
-                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)(d.k2 * nch));
+                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)nch, (unsigned)d.k2);
 #define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l); \
                               else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l); } while (0)
 #define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
