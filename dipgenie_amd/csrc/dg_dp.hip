@@ -86,7 +86,7 @@ struct DpState {
     std::vector<int64_t> dblk_first_host;
     int64_t delta_cap_entries = (int64_t)4 << 30, delta_buf_entries = 0;
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
-    int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 100;   // cost model of the per-level RC choice
+    int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 50;   // cost model of the per-level RC choice
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
     DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
     std::vector<uint64_t> digest_host;
