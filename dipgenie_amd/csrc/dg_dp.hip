@@ -46,6 +46,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t dead_first, ndead;                          // destination columns with no in-edge
     int64_t slot_first;                                 // first entry of this level in the 64-wide slot table
     int32_t fast_ok, nblocks;                           // fast kernel usable; number of 64-slot blocks (>= ngroups: giant columns take several)
+    int32_t heavy_first, n_heavy;                       // rows with more than COOP_MIN in-edges: slice of the heavy-row table
     int32_t bp_wide, bp_nt;                             // wide back-pointers on this level; stream them with non-temporal stores
 };
 
@@ -68,6 +69,8 @@ struct DpState {
     int64_t host_threads = 16;                          // option: threads used by dg_dp_load_graph's table construction
     int64_t bp_nt_min_cells = 16384;                    // option: levels with at least this many cells stream their back-pointers non-temporally
     int64_t chain_spec = 1;                             // option: speculative chain walk (0: the plain one)
+    int64_t coop_cost_ns = 0;                           // model: barrier + LDS merge of a cooperative task
+    int64_t use_coop = 1;                               // option: cooperative tasks for rows with many in-edges
     int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
@@ -88,7 +91,7 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 50;   // cost model of the per-level RC choice
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
+    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_ctrl, d_grp, d_dead, d_heavy, d_rowrec, d_slots, d_path, d_ckpt, d_chain;
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -403,9 +406,15 @@ __device__ __forceinline__ void relax_select(const int (&vals)[RC], int dl, uint
 // Lean variant: every in-degree of the level is <= 64 (no giant column blocks, row in-edges fit one per lane).
 // It is a separate function on purpose: a lone wave retires ~1 instruction per 4-8 cycles, and the extra loop
 // structure of the general variant below costs 25-30 % on the narrow levels that dominate MHC-scale graphs.
-template <int RC, bool DIGEST, int AUX, bool PROF = false>
+// COOP (per-level launches only): 0 = every row; 1 = rows with more than COOP_MIN in-edges return (they are done by the
+// cooperative region of the same launch); 2 = cooperative: the four waves of the workgroup walk a quarter of the row's
+// in-edges each, wave 0 merges the partial bests through LDS and finishes the task.  A row with 24 in-edges (one per
+// haplotype) is three dependent load rounds for one wave and sets the level's critical path; split, it is one.
+constexpr int COOP_MIN = 8;
+template <int RC, bool DIGEST, int AUX, bool PROF = false, int COOP = 0>
 __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
-                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr) {
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr,
+                                           int part = 0, uint2 *ex = nullptr) {
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
     if (PROF) q0 = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63;
@@ -422,6 +431,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
     const int evr = (int)((sl.y >> 20) & 0xFFu);                       // rank of this lane's in-edge inside its column's list
     const int du = (int)rr.y;
+    if (COOP == 1 && du > COOP_MIN) return;
     uint32_t mypu = 0;
     if (du > 2 && lane < du) mypu = A.in_edge[rr.x + lane];            // du <= 64 on this path
     if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
@@ -459,15 +469,16 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         // back to back, then the selects run; (value, ord) max is associative and commutative, so the order inside
         // a step is irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
         constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
-        for (int t = 0; t < du; t += U) {
+        const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;
+        for (int t = t_lo; t < t_hi; t += U) {
             uint32_t pu[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) pu[u] = (uint32_t)__builtin_amdgcn_readlane((int)mypu, min(t + u, du - 1));
+            for (int u = 0; u < U; ++u) pu[u] = (uint32_t)__builtin_amdgcn_readlane((int)mypu, min(t + u, t_hi - 1));
             if (act) {
                 int vals[U][RC], dl[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (t + u < du) {                                   // wave-uniform
+                    if (t + u < t_hi) {                                   // wave-uniform
                         const int iu = (int)(pu[u] & 0x7FFFFFFFu), w = (int)(pu[u] >> 31) + wv;
                         const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
                         dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
@@ -477,11 +488,30 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (t + u < du) {
+                    if (t + u < t_hi) {
                         const int wu = (int)(pu[u] >> 31);
                         relax_select<RC>(vals[u], dl[u], ord_rank(t + u, evr), r0, wu + wv, RP, bval, bord);
                     }
                 }
+            }
+        }
+    }
+    if (COOP == 2) {                                                    // partial bests of waves 1..3 -> wave 0
+        if (part > 0) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) ex[((part - 1) * RC + q) * 64 + lane] = make_uint2((uint32_t)bval[q], bord[q]);
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const uint2 o = ex[(p * RC + q) * 64 + lane];
+                const int ov = (int)o.x;
+                const bool take = (ov > bval[q]) | ((ov == bval[q]) & (o.y > bord[q]));
+                bval[q] = take ? ov : bval[q];
+                bord[q] = take ? o.y : bord[q];
             }
         }
     }
@@ -710,15 +740,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 
 // per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2), one task per wave (a 3-D grid: splitting a
 // combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
-template <int RC, bool DIGEST, bool GENERAL>
-__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl) {
-    const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
-    if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
-    const int i2 = (int)blockIdx.z, r0 = (int)blockIdx.y * RC;         // chunks of a row are neighbours in dispatch order: they share its delta row
+template <int RC, bool DIGEST, bool GENERAL, bool COOP = false>
+__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl, const int32_t *__restrict__ heavy_rows = nullptr) {
     const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
+    if (COOP && (int)blockIdx.z >= d.k2) {
+        // cooperative region (blockDim = 4 waves): workgroup (x, y, k2 + 4 h + b) = slot block 4 x + b of the h-th heavy row
+        __shared__ uint2 ex[3 * RC * 64];
+        const int hz = (int)blockIdx.z - d.k2;
+        const int g = (int)blockIdx.x * 4 + (hz & 3);
+        if (g >= d.nblocks) return;                                     // workgroup-uniform: nobody is left at the barrier
+        const int i2 = heavy_rows[d.heavy_first + (hz >> 2)];
+        sweep_task<RC, DIGEST, 0, false, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, nullptr, (int)(threadIdx.x >> 6), ex);
+        return;
+    }
+    const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
+    const int i2 = (int)blockIdx.z;
     if (GENERAL) sweep_task_general<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
-    else sweep_task<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    else sweep_task<RC, DIGEST, 0, false, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1289,7 +1330,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.level_dmax.assign(L, 0);
     std::vector<uint32_t> rowrec((size_t)nV * 4, 0);
     struct Part {
-        std::vector<int32_t> dtrans, dead_cols;
+        std::vector<int32_t> dtrans, dead_cols, heavy;
         std::vector<uint32_t> grp_begin, slots;
         std::vector<int64_t> dblk_first;
         int64_t cells = 0, units = 0, max_level_cells = 0, max_level_units = 0, delta_entries = 0, nblk = 0;
@@ -1325,6 +1366,9 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             // column groups: greedy runs of whole columns with <= 64 in-edges; a column with more gets its own group
             d.grp_first = (int32_t)grp_begin.size();
             d.dead_first = (int32_t)dead_cols.size();
+            d.heavy_first = (int32_t)P.heavy.size();
+            for (int c = 0; c < d.k2; ++c) if (in_off[d.b0 + c + 1] - in_off[d.b0 + c] > (uint32_t)COOP_MIN) P.heavy.push_back(c);
+            d.n_heavy = (int32_t)P.heavy.size() - d.heavy_first;
             {
                 uint32_t cur_size = 0;
                 for (int c = 0; c < d.k2; ++c) {
@@ -1416,7 +1460,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         }
     });
     // serial prefix over the ranges, then every range shifts its levels and copies its vectors into place
-    std::vector<int64_t> b_grp(NT + 1, 0), b_dead(NT + 1, 0), b_slot(NT + 1, 0), b_cells(NT + 1, 0), b_units(NT + 1, 0), b_delta(NT + 1, DELTA_PAD), b_blk(NT + 1, 0), b_dt(NT + 1, 0);
+    std::vector<int64_t> b_grp(NT + 1, 0), b_dead(NT + 1, 0), b_slot(NT + 1, 0), b_cells(NT + 1, 0), b_units(NT + 1, 0), b_delta(NT + 1, DELTA_PAD), b_blk(NT + 1, 0), b_dt(NT + 1, 0), b_heavy(NT + 1, 0);
     for (int t = 0; t < NT; ++t) {
         const Part &P = part[t];
         b_grp[t + 1] = b_grp[t] + (int64_t)P.grp_begin.size();
@@ -1427,6 +1471,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         b_delta[t + 1] = b_delta[t] + P.delta_entries;
         b_blk[t + 1] = b_blk[t] + P.nblk;
         b_dt[t + 1] = b_dt[t] + (int64_t)P.dtrans.size();
+        b_heavy[t + 1] = b_heavy[t] + (int64_t)P.heavy.size();
         S.max_level_cells = std::max(S.max_level_cells, P.max_level_cells);
         S.max_level_units = std::max(S.max_level_units, P.max_level_units);
         S.edge_pairs += P.edge_pairs;
@@ -1437,7 +1482,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.delta_entries = b_delta[NT];
     const int64_t nblk = b_blk[NT];
     if (b_grp[NT] >= (int64_t)1 << 31 || b_dead[NT] >= (int64_t)1 << 31) { set_error("group tables too large"); return DG_ERR_UNSUPPORTED; }
-    std::vector<int32_t> dtrans((size_t)b_dt[NT]), dead_cols((size_t)b_dead[NT]);
+    std::vector<int32_t> dtrans((size_t)b_dt[NT]), dead_cols((size_t)b_dead[NT]), heavy_rows((size_t)b_heavy[NT] + 1);
     std::vector<uint32_t> grp_begin((size_t)b_grp[NT]);
     std::vector<uint32_t> slots((size_t)b_slot[NT] * 2);         // 2 words per slot, 64 slots per block
     std::vector<int64_t> dblk_first((size_t)b_dt[NT]);
@@ -1447,12 +1492,14 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             LevelDesc &d = S.descs[l];
             d.grp_first += (int32_t)b_grp[t];
             d.dead_first += (int32_t)b_dead[t];
+            d.heavy_first += (int32_t)b_heavy[t];
             d.slot_first += b_slot[t];
             d.bp_off += b_units[t];
             if (d.delta_off >= 0) d.delta_off += b_delta[t];
         }
         std::copy(P.grp_begin.begin(), P.grp_begin.end(), grp_begin.begin() + b_grp[t]);
         std::copy(P.dead_cols.begin(), P.dead_cols.end(), dead_cols.begin() + b_dead[t]);
+        std::copy(P.heavy.begin(), P.heavy.end(), heavy_rows.begin() + b_heavy[t]);
         std::copy(P.slots.begin(), P.slots.end(), slots.begin() + 2 * b_slot[t]);
         std::copy(P.dtrans.begin(), P.dtrans.end(), dtrans.begin() + b_dt[t]);
         for (size_t q = 0; q < P.dblk_first.size(); ++q) dblk_first[(size_t)b_dt[t] + q] = P.dblk_first[q] + b_blk[t];
@@ -1577,6 +1624,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = upload(S.d_dblk_first, dblk_first.data(), 8 * dblk_first.size(), s)) return rc;
     if (int rc = upload(S.d_grp, grp_begin.data(), 4 * grp_begin.size(), s)) return rc;
     if (int rc = upload(S.d_dead, dead_cols.data(), 4 * dead_cols.size(), s)) return rc;
+    if (int rc = upload(S.d_heavy, heavy_rows.data(), 4 * heavy_rows.size(), s)) return rc;
     if (int rc = upload(S.d_rowrec, rowrec.data(), 4 * rowrec.size(), s)) return rc;
     if (int rc = upload(S.d_slots, slots.data(), 4 * slots.size(), s)) return rc;
     lap("table uploads");
@@ -1704,6 +1752,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                     // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
                     const int64_t base = (int64_t)d.k2 * d.nblocks;
                     int rc = rc_sel;
+                    bool coop = false;
                     if (S.adaptive_rc == 1) {                             // first rule: smallest RC whose waves fit a budget
                         static const int cand[5] = {1, 2, 4, 8, 16};
                         for (int q = 0; q < 5; ++q)
@@ -1713,28 +1762,42 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                         //   T(RC) = max(1, W / cap) * (t0 + dmax * RC * tg) + W * tw,   W = tasks * ceil(RP / RC) waves.
                         // First factor: rounds of resident waves; second: a wave's dependent chain (the row with the
                         // largest in-degree walks dmax in-edges with RC gathers each); last: per-wave issue overhead.
+                        // Cooperative variant (RC <= 4, lean levels): rows above COOP_MIN in-edges are walked by four waves, so
+                        // the chain is a quarter (at least COOP_MIN) while four extra workgroup slots per heavy row are launched.
                         const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
+                        const bool coop_ok = S.use_coop && S.adaptive_rc >= 3 && d.fast_ok == 1 && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
+                        const double dmax = (double)std::max(1, S.level_dmax[l]);
                         double best = 1e300;
-                        for (int q = 0; q < 11; ++q) {
-                            if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
-                            if (S.adaptive_rc == 2 && (cand[q] == 3 || cand[q] == 5 || cand[q] == 6 || cand[q] == 10 || cand[q] == 11)) continue;   // 3: all sizes
-                            const double W = (double)base * ((S.RP + cand[q] - 1) / cand[q]);
-                            const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + (double)std::max(1, S.level_dmax[l]) * cand[q] * (double)S.rc_tg_ps * 1e-3) +
-                                             W * (double)S.rc_tw_ps * 1e-3;
-                            if (T <= best) { best = T; rc = cand[q]; }        // ties: the larger RC (fewer waves)
+                        for (int pass = (coop_ok && S.use_coop == 2) ? 1 : 0; pass < (coop_ok ? 2 : 1); ++pass) {     // coop = 2 (tests): whenever possible
+                            for (int q = 0; q < 11; ++q) {
+                                if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
+                                if (S.adaptive_rc == 2 && (cand[q] == 3 || cand[q] == 5 || cand[q] == 6 || cand[q] == 10 || cand[q] == 11)) continue;   // 3: all sizes
+                                if (pass == 1 && cand[q] > 4) continue;
+                                const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
+                                const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
+                                const double W = rows * d.nblocks * ((S.RP + cand[q] - 1) / cand[q]);
+                                const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + (pass ? (double)S.coop_cost_ns : 0.0) + chain * cand[q] * (double)S.rc_tg_ps * 1e-3) +
+                                                 W * (double)S.rc_tw_ps * 1e-3;
+                                if (T <= best) { best = T; rc = cand[q]; coop = pass == 1; }   // ties: the larger RC (fewer waves)
+                            }
                         }
                     }
                     const int nch = (S.RP + rc - 1) / rc;
-                    const int wpb = (int)S.waves_per_block;               // waves (= slot blocks) per workgroup
-                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)nch, (unsigned)d.k2);
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l); } while (0)
-#define DG_FAST_RC(DG) do { switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
+                    const int wpb = coop ? 4 : (int)S.waves_per_block;    // waves (= slot blocks) per workgroup
+                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
+                    const int32_t *hv = S.d_heavy.as<int32_t>();
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); } while (0)
+#define DG_COOP(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv)
+#define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
+                                                    default: DG_COOP(4, DG); break; } break; } \
+                            switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
                                         case 4: DG_FAST(4, DG); break; case 5: DG_FAST(5, DG); break; case 6: DG_FAST(6, DG); break; \
                                         case 8: DG_FAST(8, DG); break; case 10: DG_FAST(10, DG); break; case 11: DG_FAST(11, DG); break; \
                                         case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
                                         default: DG_FAST(33, DG); break; } } while (0)
                     if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
+#undef DG_COOP
 #undef DG_FAST_RC
 #undef DG_FAST
                 } else {
@@ -1941,6 +2004,8 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "adaptive_rc")) c->dp->adaptive_rc = v;
     else if (!strcmp(key, "segment_cells")) c->dp->segment_cells = v;
     else if (!strcmp(key, "sync_every")) c->dp->sync_every = v;
+    else if (!strcmp(key, "coop")) c->dp->use_coop = v;
+    else if (!strcmp(key, "coop_cost_ns")) c->dp->coop_cost_ns = v;
     else if (!strcmp(key, "chain_spec")) c->dp->chain_spec = v;
     else if (!strcmp(key, "delta_cap_entries")) c->dp->delta_cap_entries = v > 0 ? v : (int64_t)4 << 30;   // takes effect at the next load
     else if (!strcmp(key, "rc_cap")) c->dp->rc_cap = v > 0 ? v : 16384;

@@ -131,11 +131,11 @@ def test_dp_random_levelized(gpu_ctx, seed):
     _dp_both(gpu_ctx, g)
 
 
-@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive", "budget_rc", "model_rc_pow2"])
+@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive", "budget_rc", "model_rc_pow2", "no_coop", "force_coop"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
     """the generic fallback sweep, the one-XCD team kernel and the fixed-RC launch must all give the oracle's answer"""
     opts = {"generic": {"fast": 0}, "team": {"team": 1, "team_min_levels": 4, "team_max_tasks": 4096}, "no_adaptive": {"adaptive_rc": 0},
-            "budget_rc": {"adaptive_rc": 1}, "model_rc_pow2": {"adaptive_rc": 2}}[mode]
+            "budget_rc": {"adaptive_rc": 1}, "model_rc_pow2": {"adaptive_rc": 2}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -145,8 +145,12 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             out = gpu_ctx.dp_solve(g)
             ref = orc.dp_solve(g)
             assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"]), (mode, seed)
+        if mode in ("no_coop", "force_coop"):        # fan-in rows (the cooperative tasks' subject), with all level digests
+            for seed, kw in [(5, dict(max_width=30, n_levels=120, R=18, p_w1=0.3, p_colour=0.5)), (6, dict(max_width=60, n_levels=40, R=32, p_w1=0.6)),
+                             (7, dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8))]:
+                _dp_both(gpu_ctx, graphgen.random_levelized(7100 + seed, **kw))
     finally:
-        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 3}.items():
+        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 3, "coop": 1}.items():
             gpu_ctx.dp_set_option(k, v)
 
 
