@@ -575,9 +575,10 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
 }
 
 // General variant: any in-degree (see the notes on giant columns above); used for levels tagged fast_ok == 2.
-template <int RC, bool DIGEST, int AUX, bool PROF = false>
+template <int RC, bool DIGEST, int AUX, bool PROF = false, int COOP = 0>
 __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
-                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr) {
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, unsigned long long *pp = nullptr,
+                                           int part = 0, uint2 *ex = nullptr) {
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
     if (PROF) q0 = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63;
@@ -599,6 +600,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
     const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
     const int dT = has_delta ? d.T : 0;
     const int du = (int)rr.y;
+    if (COOP == 1 && du > COOP_MIN) return;
+    const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;   // this wave's share of the row's in-edges
     if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); q1 = __builtin_amdgcn_s_memtime(); }
     int bval[RC];
     uint32_t bord[RC];
@@ -643,8 +646,8 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             // the selects run; (value, ord) max is associative and commutative, so the order inside a step is
             // irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
             constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
-            for (int c0 = 0; c0 < du; c0 += 64) {
-                const int dc = min(64, du - c0);
+            for (int c0 = t_lo; c0 < t_hi; c0 += 64) {
+                const int dc = min(64, t_hi - c0);
                 uint32_t mypu = 0;
                 if (lane < dc) mypu = A.in_edge[rr.x + c0 + lane];
                 for (int t = 0; t < dc; t += U) {
@@ -672,6 +675,25 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
                         }
                     }
                 }
+            }
+        }
+    }
+    if (COOP == 2) {                                                    // partial bests of waves 1..3 -> wave 0 (see sweep_task)
+        if (part > 0) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) ex[((part - 1) * RC + q) * 64 + lane] = make_uint2((uint32_t)bval[q], bord[q]);
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const uint2 o = ex[(p * RC + q) * 64 + lane];
+                const int ov = (int)o.x;
+                const bool take = (ov > bval[q]) | ((ov == bval[q]) & (o.y > bord[q]));
+                bval[q] = take ? ov : bval[q];
+                bord[q] = take ? o.y : bord[q];
             }
         }
     }
@@ -752,13 +774,14 @@ __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDes
         const int g = (int)blockIdx.x * 4 + (hz & 3);
         if (g >= d.nblocks) return;                                     // workgroup-uniform: nobody is left at the barrier
         const int i2 = heavy_rows[d.heavy_first + (hz >> 2)];
-        sweep_task<RC, DIGEST, 0, false, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, nullptr, (int)(threadIdx.x >> 6), ex);
+        if (GENERAL) sweep_task_general<RC, DIGEST, 0, false, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, nullptr, (int)(threadIdx.x >> 6), ex);
+        else sweep_task<RC, DIGEST, 0, false, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, nullptr, (int)(threadIdx.x >> 6), ex);
         return;
     }
     const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
     const int i2 = (int)blockIdx.z;
-    if (GENERAL) sweep_task_general<RC, DIGEST, 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    if (GENERAL) sweep_task_general<RC, DIGEST, 0, false, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
     else sweep_task<RC, DIGEST, 0, false, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
 }
 
@@ -1765,7 +1788,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                         // Cooperative variant (RC <= 4, lean levels): rows above COOP_MIN in-edges are walked by four waves, so
                         // the chain is a quarter (at least COOP_MIN) while four extra workgroup slots per heavy row are launched.
                         const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
-                        const bool coop_ok = S.use_coop && S.adaptive_rc >= 3 && d.fast_ok == 1 && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
+                        const bool coop_ok = S.use_coop && S.adaptive_rc >= 3 && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
                         const double dmax = (double)std::max(1, S.level_dmax[l]);
                         double best = 1e300;
                         for (int pass = (coop_ok && S.use_coop == 2) ? 1 : 0; pass < (coop_ok ? 2 : 1); ++pass) {     // coop = 2 (tests): whenever possible
@@ -1788,7 +1811,8 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                     const int32_t *hv = S.d_heavy.as<int32_t>();
 #define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); \
                               else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); } while (0)
-#define DG_COOP(RCV, DG) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv)
+#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
 #define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
                                                     default: DG_COOP(4, DG); break; } break; } \
                             switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
