@@ -2,18 +2,21 @@
 //
 // Replaces the level loop + sink read-out of Approximator::diploid_dp_approximation_solver
 // (/root/reference/src/approximator.cpp:532-716, 757-785).  Design:
-//   * gather form: one work-item per destination cell (i2, j2, r2) of level l+1, reducing over
-//     in(u2) x in(v2); in-edges are stored sorted by source position, so a strict '>' scan
-//     reproduces the reference's take-if total order (value desc, pred_i asc, pred_j asc, :657-659)
-//     without locks or atomics, and no destination is ever "reset" (:565-576 disappears);
-//   * rolling value state is 4 B/cell, layout [i][r][j] (j fastest: lanes of a wave run along the
-//     destination columns and read (near-)consecutive addresses); s_het / edge chains are not carried (reference cell = 40 B).  Instead every cell
-//     streams one 4-byte back-pointer (pred_i | pred_j<<15 | wu<<30 | wv<<31) to HBM and a
-//     traceback kernel walks the lattice from the sink, emitting the weighted-edge lists (:757-764,
-//     :673-692) and re-deriving s_het from the colour lists of the L winning edge pairs;
-//   * score deltas (:604-624) do not depend on r nor on other levels: one launch fills, for every
-//     transition that touches a colour, the T x T matrix delta[e_u][e_v] (uint16), T = #in-edges of
-//     the destination level; colourless transitions (73 % on MHC_4) skip the lookup.
+//   * gather form: every destination cell (i2, j2, r2) of level l+1 reduces over in(u2) x in(v2) -- one wave per
+//     (destination row, group of <= 64 column in-edges, chunk of recombination counts), lanes on the column
+//     in-edges; in-edges are stored sorted by source position, so a lexicographic max over (value, in-edge ranks)
+//     reproduces the reference's take-if total order (value desc, pred_i asc, pred_j asc, :657-659) without locks
+//     or atomics, and no destination is ever "reset" (:565-576 disappears);
+//   * rolling value state is 4 B/cell, layout [i][r][j] (j fastest: lanes of a wave run along the destination
+//     columns and read (near-)consecutive addresses); s_het / edge chains are not carried (reference cell = 40 B).
+//     Instead every cell streams one 2-byte back-pointer (ranks of the winning in-edges) to HBM and a traceback
+//     walks the lattice from the sink, emitting the weighted-edge lists (:757-764, :673-692) and re-deriving
+//     s_het from the colour lists of the L winning edge pairs;
+//   * score deltas (:604-624) do not depend on r nor on other levels: a launch fills, for every transition that
+//     touches a colour, the T x T matrix delta[e_u][e_v] (uint16), T = #in-edges of the destination level;
+//     colourless transitions (73 % on MHC_4) skip the lookup;
+//   * one launch per level (the levels are a dependency chain); the host picks the chunk size RC per level from a
+//     cost model and gives rows with many in-edges cooperative workgroups.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1312,7 +1315,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
             }
         }
         for (int v = da; v < db; ++v)     // parallel edges must carry equal weights (always true for graphs built by
-            for (uint32_t e = in_off[v] + 1; e < in_off[v + 1]; ++e)   // Approximator::solve; see DESIGN.md s3.4)
+            for (uint32_t e = in_off[v] + 1; e < in_off[v + 1]; ++e)   // Approximator::solve; see DESIGN.md s3.5)
                 if ((in_edge[e] & 0x7FFFFFFFu) == (in_edge[e - 1] & 0x7FFFFFFFu) && in_edge[e] != in_edge[e - 1]) {
                     tfail(t, DG_ERR_UNSUPPORTED, "parallel edges with different weights into vertex %d: tie order would be schedule dependent", v);
                     return;
