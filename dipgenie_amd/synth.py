@@ -250,6 +250,37 @@ def mosaic_panel(base_gfa, out_gfa, out_reads, n_total=24, seed=24, switch_bp=25
                 hap_bp=[len(h) for h in haps])
 
 
+def prefix_panel(gfa_in, out_gfa, out_reads, frac, read_seed=4, coverage=4.0, read_len=150, sub_rate=0.002, sample=(5, 6)):
+    """The first `frac` of a panel as a panel of its own: every walk is cut at the first segment, about `frac` of the way
+    along walk 0, that ALL walks traverse (so the cut graph keeps a single sink); segments and links beyond it are
+    dropped, reads are re-simulated (same recipe as the full panel) from the cut sample haplotypes.  Used as the bounded
+    sample of the bench workload for the reference binary.  Returns a dict of sizes."""
+    names, seqs, links, walks = parse_gfa(gfa_in)
+    sets = [set(w) for (_, _, w) in walks]
+    w0 = walks[0][2]
+    cut = None
+    for t in range(max(1, int(frac * len(w0))), len(w0)):
+        if all(w0[t] in st for st in sets):
+            cut = w0[t]
+            break
+    if cut is None:
+        raise ValueError("no segment shared by all walks after the requested fraction")
+    new_walks = [(n, h, w[: w.index(cut) + 1]) for (n, h, w) in walks]
+    keep = sorted(set(v for (_, _, w) in new_walks for v in w))
+    remap = {v: i for i, v in enumerate(keep)}
+    seqs2 = [seqs[v] for v in keep]
+    links2 = [(remap[a], remap[b]) for (a, b) in links if a in remap and b in remap and a != cut]
+    walks2 = [(n, h, [remap[v] for v in w]) for (n, h, w) in new_walks]
+    write_gfa(out_gfa, seqs2, links2, walks2)
+    rrng = np.random.default_rng(read_seed)
+    haps = [b"".join(seqs2[v] for v in walks2[h][2]).upper() for h in sample]
+    n_reads = int(coverage * sum(len(h) for h in haps) / 2 / read_len)
+    reads = simulate_reads(rrng, haps, n_reads, read_len, sub_rate)
+    write_fasta(out_reads, reads)
+    return dict(n_segments=len(seqs2), n_links=len(links2), n_walks=len(walks2), n_reads=len(reads), hap_bp=[len(h) for h in haps],
+                frac=frac)
+
+
 def ensure_mhc24(cache_dir, base_gfa=None):
     """Generate (once) the config-3 workload under cache_dir; returns (gfa_path, reads_path, info)."""
     import json
