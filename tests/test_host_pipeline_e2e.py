@@ -51,3 +51,28 @@ def test_e2e_mhc4_diploid(built_cpu, tmp_path):
 def test_e2e_mhc4_haploid(built_cpu, tmp_path):
     fa, summ = run_case(built_cpu, CASES["mhc4_p1"], tmp_path)
     check(CASES["mhc4_p1"], fa, summ)
+
+
+def test_prefix_panel_is_a_panel(built_cpu, tmp_path):
+    """synth.prefix_panel (the bounded sample bench.py hands to the reference binary): every walk ends at the same
+    segment, links stay inside the kept segments and never leave the cut segment, and the host pipeline solves it"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from dipgenie_amd import synth
+    src = os.path.join(ROOT, CASES["c5s"]["gfa"])
+    gfa, fa = str(tmp_path / "pre.gfa"), str(tmp_path / "pre.fa")
+    info = synth.prefix_panel(src, gfa, fa, 0.5, sample=(0, 1), coverage=6.0, read_len=80)
+    names, seqs, links, walks = synth.parse_gfa(gfa)
+    full = synth.parse_gfa(src)
+    assert info["n_walks"] == len(walks) == len(full[3]) and 0 < len(seqs) < len(full[1])
+    ends = {w[-1] for (_, _, w) in walks}
+    assert len(ends) == 1
+    cut = ends.pop()
+    assert all(0 <= a < len(seqs) and 0 <= b < len(seqs) and a != cut for a, b in links)
+    for (_, _, w) in walks:
+        assert w.count(cut) == 1 and all((a, b) in set(links) for a, b in zip(w, w[1:]))
+    out, js = tmp_path / "o.fa", tmp_path / "o.json"
+    subprocess.run([built_cpu, "-q", "-t4", "-p2", "-R4", "-g", gfa, "-r", fa, "-o", str(out), "-J", str(js)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    summ = json.load(open(js))
+    assert summ["len1"] > 0 and summ["len2"] > 0 and open(out).read().startswith(">sol_1 bp:")
