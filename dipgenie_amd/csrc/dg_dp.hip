@@ -648,7 +648,7 @@ __device__ __forceinline__ void sweep_task_general(const FastArgs &A, const Leve
             // with readlane; U in-edges per step -- all their loads (U deltas + U*RC values) go out back to back, then
             // the selects run; (value, ord) max is associative and commutative, so the order inside a step is
             // irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
-            constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
+            constexpr int U = RC >= 4 ? 2 : 4;                          // (deeper steps spill SGPRs in this variant)
             for (int c0 = t_lo; c0 < t_hi; c0 += 64) {
                 const int dc = min(64, t_hi - c0);
                 uint32_t mypu = 0;
