@@ -9,20 +9,46 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <string>
+#include <thread>
 
 #include "pipeline.hpp"
 
+// The device context is created on a side thread while the main thread reads the GFA and the reads (HIP start-up is
+// ~0.3 s, the two overlap); the first backend call joins it.
+struct LazyCtx {
+    std::thread th;
+    dg_ctx *ctx = nullptr;
+    std::string err;
+    bool joined = false;
+    void start(int device) {
+        th = std::thread([this, device] { ctx = dg_create(device); if (!ctx) err = dg_last_error(); });
+    }
+    dg_ctx *get() {
+        if (!joined) { th.join(); joined = true; }
+        return ctx;
+    }
+};
+static LazyCtx g_lazy;
+static const char *b_last_error() { return g_lazy.joined && !g_lazy.ctx ? g_lazy.err.c_str() : dg_last_error(); }
+
 static int b_sketch_reads(void *c, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **cnt, int64_t *nd) {
-    return dg_sketch_reads((dg_ctx *)c, b, off, n, k, w, h, cnt, nd);
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_sketch_reads(x, b, off, n, k, w, h, cnt, nd) : DG_ERR_NO_DEVICE;
 }
 static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) {
-    return dg_sketch_haplotype((dg_ctx *)c, s, len, k, w, h, p, n);
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_sketch_haplotype(x, s, len, k, w, h, p, n) : DG_ERR_NO_DEVICE;
 }
-static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
-static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reservation (4 B/cell) with the host stages
-    const double bytes = 4.0 * (double)est_cells;     // a low estimate is harmless: the rest is mapped during the sweep
-    if (bytes >= 4e9) dg_dp_prealloc((dg_ctx *)c, bytes > 8e18 ? 0 : (int64_t)bytes);   // small lattices allocate instantly anyway
+static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) {
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_dp_solve_diploid(x, g, r) : DG_ERR_NO_DEVICE;
+}
+static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reservation (2 B/cell) with the host stages
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    const double bytes = 2.0 * (double)est_cells;     // a low estimate is harmless: the rest is mapped before the sweep starts
+    if (x && bytes >= 4e9) dg_dp_prealloc(x, bytes > 8e18 ? 0 : (int64_t)bytes);   // small lattices allocate instantly anyway
 }
 
 static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
@@ -73,18 +99,19 @@ int main(int argc, char **argv) {
         usage(stderr, p.opt);
         return 1;
     }
-    dg_ctx *ctx = dg_create(device);
-    if (!ctx) { fprintf(stderr, "[E::main] %s\n", dg_last_error()); return 2; }
-    p.be.ctx = ctx;
+    const double t0 = dg::now_s();
+    g_lazy.start(device);
+    p.be.ctx = &g_lazy;
     p.be.sketch_reads = b_sketch_reads;
     p.be.sketch_haplotype = b_sketch_hap;
     p.be.dp_solve_diploid = b_dp;
     p.be.free_buf = dg_free;
     p.be.hint_dp_soon = b_hint;
-    p.be.last_error = dg_last_error;
-    double t0 = dg::now_s();
+    p.be.last_error = b_last_error;
     std::string err;
     int rc = p.run(err);
+    dg_ctx *ctx = g_lazy.get();
+    if (!ctx) { fprintf(stderr, "[E::main] %s\n", g_lazy.err.c_str()); return 2; }   // no gfx950 device: no CPU fallback
     if (rc != 0) { fprintf(stderr, "[E::main] %s\n", err.c_str()); dg_destroy(ctx); return 1; }
     dg_dp_timing tm;
     if (p.opt.ploidy == 2 && dg_dp_get_timing(ctx, &tm) == DG_OK)
@@ -106,6 +133,13 @@ int main(int argc, char **argv) {
         }
     }
     fprintf(stderr, "[M::main] Real time: %.3f sec\n", dg::now_s() - t0);
+    // Everything is written and closed.  Tearing down tens of GB of device chunks and host vectors one by one costs
+    // ~0.4 s that the operating system does for free at exit; DG_CLEAN_EXIT=1 keeps the orderly path (leak checkers).
+    if (!getenv("DG_CLEAN_EXIT")) {
+        std::cout.flush();
+        fflush(nullptr);
+        _exit(0);
+    }
     dg_destroy(ctx);
     return 0;
 }
