@@ -982,28 +982,40 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     }
     if (!opt.quiet && g.level_off[1] - g.level_off[0] > 1) std::cout << "There is more than one source on level zero!" << std::endl;
     // the flat graph already is the dg_dp_graph layout (vertex ids are level-sorted: ExpandedGraph.hpp:360-407)
+    // Topology arrays are handed to the device library in place (no copies); only the HOM / HET colour CSR (:431-453,
+    // lists are sorted-unique already) is new: counts, prefix sums, fill -- in parallel over vertex blocks.
     dpg = DpGraphStorage();
-    dpg.level_off = g.level_off;
-    dpg.out_off = g.adj_off;
-    dpg.out_dst = g.adj_dst;
-    dpg.out_w = g.adj_w;
     dpg.hom_off.assign((size_t)nV + 1, 0);
     dpg.het_off.assign((size_t)nV + 1, 0);
     if (!opt.quiet) std::cout << "Creating hetro/hom-zygous colors per vertex lists" << std::endl;
-    dpg.hom_col.reserve(g.col_pool.size());
-    dpg.het_col.reserve(g.col_pool.size());
-    for (int v = 0; v < nV; ++v) {                                     // :431-453 (lists are sorted-unique already)
+    for (int c : g.col_pool) (void)color_homo_bv.at(c);                // same out_of_range behaviour as the reference's .at()
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < nV; ++v) {
+        int64_t nh = 0;
+        for (int64_t q = g.col_off[v]; q < g.col_off[v + 1]; ++q) nh += color_homo_bv[g.col_pool[q]] == 1;
+        dpg.hom_off[v + 1] = nh;
+        dpg.het_off[v + 1] = (g.col_off[v + 1] - g.col_off[v]) - nh;
+    }
+    for (int v = 0; v < nV; ++v) { dpg.hom_off[v + 1] += dpg.hom_off[v]; dpg.het_off[v + 1] += dpg.het_off[v]; }
+    dpg.hom_col.resize((size_t)dpg.hom_off[nV]);
+    dpg.het_col.resize((size_t)dpg.het_off[nV]);
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < nV; ++v) {
+        int64_t ph = dpg.hom_off[v], pt = dpg.het_off[v];
         for (int64_t q = g.col_off[v]; q < g.col_off[v + 1]; ++q) {
             const int c = g.col_pool[q];
-            if (color_homo_bv.at(c) == 1) dpg.hom_col.push_back(c); else dpg.het_col.push_back(c);
+            if (color_homo_bv[c] == 1) dpg.hom_col[ph++] = c; else dpg.het_col[pt++] = c;
         }
-        dpg.hom_off[v + 1] = (int64_t)dpg.hom_col.size();
-        dpg.het_off[v + 1] = (int64_t)dpg.het_col.size();
     }
     sum.n_levels = L;
     sum.n_vertices = nV;
     stamp("dp_prologue_flatten", t0);
-    if (!opt.dump_prefix.empty()) dpg.save(opt.dump_prefix + ".dpg", opt.R);
+    if (!opt.dump_prefix.empty()) {                                    // the dump wants the topology too
+        dpg.level_off = g.level_off; dpg.out_off = g.adj_off; dpg.out_dst = g.adj_dst; dpg.out_w = g.adj_w;
+        dpg.save(opt.dump_prefix + ".dpg", opt.R);
+        std::vector<int32_t>().swap(dpg.level_off); std::vector<int64_t>().swap(dpg.out_off);
+        std::vector<int32_t>().swap(dpg.out_dst); std::vector<uint8_t>().swap(dpg.out_w);
+    }
     if (opt.dump_only) { err = "dump_only"; return 1; }
 
     // ---- the level loop + sink read-out: DEVICE (approximator.cpp:532-716, 774-785) ----
@@ -1013,6 +1025,8 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     const int cap = R + 8;
     std::vector<int32_t> p1f(cap), p1t(cap), p2f(cap), p2t(cap);
     dg_dp_graph view = dpg.view(R);
+    view.n_vertices = nV; view.n_levels = L;
+    view.level_off = g.level_off.data(); view.out_off = g.adj_off.data(); view.out_dst = g.adj_dst.data(); view.out_w = g.adj_w.data();
     dg_dp_result res;
     memset(&res, 0, sizeof(res));
     res.p1_from = p1f.data(); res.p1_to = p1t.data(); res.p2_from = p2f.data(); res.p2_to = p2t.data();
@@ -1124,11 +1138,18 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
         std::cout << "recombinations in P1: " << r1 << ", recombinations in P2: " << r2 << ", bp of P1: " << hap_seq[0].length()
                   << ", bp of P2: " << hap_seq[1].length() << std::endl;                 // :1307-1308
     {
-        std::ofstream f(opt.hap_file, std::ios::out);                                    // :1314-1325
-        f << ">" << "sol_1" << " bp:" << hap_seq[0].size() << std::endl;
-        for (size_t i = 0; i < hap_seq[0].size(); i += 80) f << hap_seq[0].substr(i, 80) << std::endl;
-        f << ">" << "sol_2" << " bp:" << hap_seq[1].size() << std::endl;
-        for (size_t i = 0; i < hap_seq[1].size(); i += 80) f << hap_seq[1].substr(i, 80) << std::endl;
+        // :1314-1325 -- same bytes (80 columns, '\n' line ends), assembled in memory and written once instead of one
+        // flushed line at a time
+        std::string text;
+        text.reserve(hap_seq[0].size() + hap_seq[1].size() + (hap_seq[0].size() + hap_seq[1].size()) / 80 + 128);
+        for (int q = 0; q < 2; ++q) {
+            text += q == 0 ? ">sol_1 bp:" : ">sol_2 bp:";
+            text += std::to_string(hap_seq[q].size());
+            text += '\n';
+            for (size_t i = 0; i < hap_seq[q].size(); i += 80) { text.append(hap_seq[q], i, 80); text += '\n'; }
+        }
+        std::ofstream f(opt.hap_file, std::ios::out | std::ios::binary);
+        f.write(text.data(), (std::streamsize)text.size());
         f.close();
     }
     stamp("traceback+write", t0);
