@@ -461,7 +461,9 @@ void ExpandedGraph::permute(const std::vector<int32_t> &order) {
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i) new_idx[order[i]] = i;
     std::vector<int64_t> noff((size_t)nn + 1, 0);
-    for (int32_t i = 0; i < nn; ++i) noff[i + 1] = noff[i] + deg(order[i]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nn; ++i) noff[i + 1] = deg(order[i]);      // (random gathers in parallel, the running sum alone is cheap)
+    for (int32_t i = 0; i < nn; ++i) noff[i + 1] += noff[i];
     lap("new_idx+noff");
     std::vector<int32_t> ndst(adj_dst.size());
     std::vector<uint8_t> nw(adj_w.size());
@@ -481,13 +483,17 @@ void ExpandedGraph::permute(const std::vector<int32_t> &order) {
     haplotype.swap(nh); orig_off.swap(noo); orig_len.swap(nol);
     if ((int32_t)level.size() == nn) {
         std::vector<int32_t> nl(nn);
+#pragma omp parallel for schedule(static)
         for (int32_t i = 0; i < nn; ++i) nl[i] = level[order[i]];
         level.swap(nl);
     }
     lap("vertex arrays");
     std::vector<int64_t> nco((size_t)nn + 1, 0);
-    for (int32_t i = 0; i < nn; ++i) nco[i + 1] = nco[i] + ncol(order[i]);
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < nn; ++i) nco[i + 1] = ncol(order[i]);
+    for (int32_t i = 0; i < nn; ++i) nco[i + 1] += nco[i];
     std::vector<int32_t> ncp(col_pool.size());
+#pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i)
         std::copy(col_pool.begin() + col_off[order[i]], col_pool.begin() + col_off[order[i] + 1], ncp.begin() + nco[i]);
     col_off.swap(nco); col_pool.swap(ncp);
