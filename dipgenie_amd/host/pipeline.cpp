@@ -13,6 +13,7 @@
 #include <numeric>
 #include <queue>
 #include <stdexcept>
+#include <string_view>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -346,39 +347,52 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     std::vector<std::vector<int32_t>> vpool_c(n_chunks);
 #pragma omp parallel for num_threads(opt.threads) schedule(dynamic, 1)
     for (int c = 0; c < n_chunks; ++c) {
-        std::vector<std::string> keys;
-        std::vector<int32_t> order, grp;
+        std::string arena;                                             // keys "v0_v1_..._" back to back (:600-603)
+        std::vector<uint32_t> koff;
+        std::vector<int32_t> order, grp, byhap;
+        auto key = [&](int32_t t) { return std::string_view(arena.data() + koff[t], koff[t + 1] - koff[t]); };
         auto &occs_l = occs_c[c];
         auto &vpool_l = vpool_c[c];
         for (int32_t r = chunk_lo[c]; r < chunk_lo[c + 1]; ++r) {
             const int64_t b = bucket_off[r], e = bucket_off[r + 1];
             if (b == e) continue;
             const int32_t n = (int32_t)(e - b);
-            keys.resize(n);
-            for (int32_t t = 0; t < n; ++t) {                          // :600-603 "v0_v1_..._"
+            arena.clear();
+            koff.assign(1, 0);
+            for (int32_t t = 0; t < n; ++t) {
                 const Raw &o = raw[b + t];
                 const auto &ix = kmer_index[o.h];
-                std::string &s = keys[t];
-                s.clear();
-                for (uint32_t q = ix.voff[o.m]; q < ix.voff[o.m + 1]; ++q) { s += std::to_string(ix.v[q]); s += '_'; }
+                for (uint32_t q = ix.voff[o.m]; q < ix.voff[o.m + 1]; ++q) {
+                    char buf[12];
+                    int len = 0;
+                    uint32_t x = (uint32_t)ix.v[q];                     // vertex ids are non-negative
+                    do { buf[len++] = (char)('0' + x % 10); x /= 10; } while (x);
+                    while (len) arena += buf[--len];
+                    arena += '_';
+                }
+                koff.push_back((uint32_t)arena.size());
             }
             order.resize(n);
             std::iota(order.begin(), order.end(), 0);
             // std::map<std::string,...> iteration = lexicographic on the key; inside a key, push order
-            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return keys[x] < keys[y]; });
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key(x) < key(y); });
             bool all_haps = false;                                     // :615-622
             for (int32_t i = 0; i < n;) {
                 int32_t j = i + 1;
-                while (j < n && keys[order[j]] == keys[order[i]]) ++j;
+                while (j < n && key(order[j]) == key(order[i])) ++j;
                 if ((float)(j - i) >= thr) { all_haps = true; break; }
                 i = j;
             }
             if (all_haps) continue;                                    // :624-632 id dropped entirely
             // Anchor_hits_1[r][h] in map-iteration order, then std::sort per (r,h) (:641-663)
-            for (uint32_t h = 0; h < num_walks; ++h) {
-                grp.clear();
-                for (int32_t i = 0; i < n; ++i) if (raw[b + order[i]].h == (int32_t)h) grp.push_back(order[i]);
-                if (grp.empty()) continue;
+            byhap = order;                                             // haplotype ascending, map-iteration order inside one
+            std::stable_sort(byhap.begin(), byhap.end(), [&](int32_t x, int32_t y) { return raw[b + x].h < raw[b + y].h; });
+            for (int32_t g0 = 0; g0 < n;) {
+                const int32_t h = raw[b + byhap[g0]].h;
+                int32_t g1 = g0;
+                while (g1 < n && raw[b + byhap[g1]].h == h) ++g1;
+                grp.assign(byhap.begin() + g0, byhap.begin() + g1);
+                g0 = g1;
                 const auto &ix = kmer_index[h];
                 std::sort(grp.begin(), grp.end(), [&](int32_t x, int32_t y) {
                     const uint32_t mx = raw[b + x].m, my = raw[b + y].m;
