@@ -75,6 +75,7 @@ struct DpState {
     int64_t coop_cost_ns = 0;                           // model: barrier + LDS merge of a cooperative task
     int64_t use_coop = 1;                               // option: cooperative tasks for rows with many in-edges
     int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
+    int64_t warm_ahead = 128;                           // option: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
     std::vector<Segment> schedule;
@@ -924,6 +925,19 @@ __global__ __launch_bounds__(256) void dp_warm_kernel(const uint4 *__restrict__ 
     if (i < n) { uint4 v = p[i]; asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 }
 
+// Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
+// levels through the memory-side Infinity Cache.  Every table byte is read exactly once per pass, so without this each
+// level's two dependent load rounds go all the way to HBM; the batch is a few MB, read at full chip bandwidth.
+struct WarmRanges { const char *p[4]; long long n16[4]; };            // start (16-byte aligned down) and length in 16-byte units
+__global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 *p = (const uint4 *)W.p[q];
+        for (long long i = tid; i < W.n16[q]; i += nth) { uint4 v = p[i]; asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+    }
+}
+
 __global__ __launch_bounds__(64) void dp_trace_chain_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
                                                             const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
                                                             const int32_t *__restrict__ final_val /* non-null on the first call */,
@@ -1730,6 +1744,31 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         }
         S.cur_win = w;
     };
+    auto warm_tables = [&](int q0, int q1) {             // graph tables of destination levels [q0, q1) -> Infinity Cache
+        const LevelDesc &da = S.descs[q0], &db = S.descs[q1 - 1];
+        WarmRanges W{};
+        auto put = [&](int q, const void *base, int64_t b0, int64_t b1) {       // byte range [b0, b1) behind base
+            const uintptr_t a = ((uintptr_t)base + (uintptr_t)b0) & ~(uintptr_t)15, e = ((uintptr_t)base + (uintptr_t)b1) & ~(uintptr_t)15;
+            W.p[q] = (const char *)a; W.n16[q] = e > a ? (long long)((e - a) >> 4) : 0;
+        };
+        put(0, F.rowrec, 16 * (int64_t)da.b0, 16 * ((int64_t)db.b0 + db.k2));
+        put(1, F.slots, 8 * da.slot_first, 8 * (db.slot_first + (int64_t)db.nblocks * 64));
+        put(2, F.in_edge, 4 * (int64_t)da.in_base, 4 * ((int64_t)db.in_base + db.T));
+        int64_t d0 = -1, d1 = -1;
+        for (int q = q0; q < q1; ++q) {
+            const LevelDesc &dq = S.descs[q];
+            if (dq.delta_off < 0 || S.level_win[q] != S.cur_win) continue;
+            const int64_t e = dq.delta_off + (int64_t)dq.T * dq.T;
+            d0 = d0 < 0 ? dq.delta_off : std::min(d0, dq.delta_off);
+            d1 = std::max(d1, e);
+        }
+        if (d0 >= 0) put(3, F.delta, 2 * d0, 2 * d1);
+        long long tot = 0;
+        for (int q = 0; q < 4; ++q) tot += W.n16[q];
+        if (tot <= 0) return;
+        const unsigned grid = (unsigned)std::min<long long>((tot + 255) / 256, 2048);
+        hipLaunchKernelGGL(dp_warm_tables_kernel, dim3(grid), dim3(256), 0, s, W);
+    };
     auto sweep_range = [&](int lb, int le, uint16_t *bp_biased) -> int {
         A.bp = bp_biased; F.bp = bp_biased;
         // runs of narrow levels may go to the one-XCD team kernel (one launch per run, optional); every other level
@@ -1770,6 +1809,11 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
             for (int l = seg.begin; l < seg.end; ++l) {
                 LevelDesc &d = S.descs[l];
                 if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
+                if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0) {
+                    // tables of the batch after this one (and, at the start of a range, of this one too)
+                    const int q0 = l == lb ? l : (int)std::min<int64_t>(l + S.warm_ahead, le), q1 = (int)std::min<int64_t>(l + 2 * S.warm_ahead, le);
+                    if (q1 > q0) warm_tables(q0, q1);
+                }
                 // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
                 // non-temporal ones that keep the once-written lattice out of the L2
                 d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
@@ -2040,6 +2084,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "rc_tg_ps")) c->dp->rc_tg_ps = v;
     else if (!strcmp(key, "rc_tw_ps")) c->dp->rc_tw_ps = v;
     else if (!strcmp(key, "warm_rows")) c->dp->warm_rows = v;
+    else if (!strcmp(key, "warm_ahead")) c->dp->warm_ahead = v < 0 ? 0 : v;
     else if (!strcmp(key, "bp_nt_min_cells")) c->dp->bp_nt_min_cells = v;
     else if (!strcmp(key, "host_threads")) c->dp->host_threads = v < 1 ? 1 : v;
     else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (in 16-bit back-pointer units = cells on ordinary levels; default 2^32 = 8 GB)

@@ -701,6 +701,7 @@ bool DpGraphStorage::load(const std::string &path, int &R) {
 // haploid DP  (approximator.cpp:44-168) -- CPU by design
 // ======================================================================================
 std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
+    double th0 = now_s();
     int n = g.n;
     const std::size_t N = (std::size_t)n * (R + 1);
     std::vector<int> dp(N, 0), back_vtx(N, -1), back_r(N, -1);         // :50-52 (0, not -inf: quirk kept)
@@ -717,28 +718,33 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
                     back_r[idx(v, r + w_uv)] = r;
                 }
             }
-    std::vector<int> colors_by_r;
-    std::vector<std::map<int, int>> occ_count_by_r;
-    for (int r = 0; r <= R; r++) {                                     // :74-102
-        std::unordered_set<int> true_colours;
-        std::map<int, int> occ_count;
-        int cur_vtx = n - 1, cur_r = r;
+    const bool dbg_h = getenv("DG_DEBUG") != nullptr;
+    if (dbg_h) fprintf(stderr, "[dg::haploid] scatter DP %.3f s\n", now_s() - th0);
+    th0 = now_s();
+    // :74-113.  The reference fills an unordered_set and a std::map per r; only the number of distinct colours on the
+    // path and (for the certificate line) the mean occurrence count are used: flat counters per r, the R+1 walks in parallel.
+    int32_t max_col = -1;
+    for (int32_t c : g.col_pool) max_col = std::max(max_col, c);
+    std::vector<int> colors_by_r(R + 1, 0);
+    std::vector<float> avg_by_r(R + 1, 0.f);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(opt.threads > 0 ? opt.threads : 1)
+    for (int r = 0; r <= R; r++) {
+        std::vector<int32_t> cnt((size_t)max_col + 1, 0);
+        int cur_vtx = n - 1, cur_r = r, distinct = 0;
         while (cur_vtx != -1) {
-            for (int64_t q = g.col_off[cur_vtx]; q < g.col_off[cur_vtx + 1]; ++q) { true_colours.insert(g.col_pool[q]); occ_count[g.col_pool[q]] += 1; }
+            for (int64_t q = g.col_off[cur_vtx]; q < g.col_off[cur_vtx + 1]; ++q) distinct += (cnt[g.col_pool[q]]++ == 0);
             int temp_vtx = cur_vtx;
             cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
             cur_r = back_r[idx(temp_vtx, cur_r)];
         }
-        colors_by_r.push_back((int)true_colours.size());
-        occ_count_by_r.push_back(occ_count);
+        colors_by_r[r] = distinct;
+        float avg = 0;                                                 // :106-111: float sum in ascending colour order
+        for (int32_t c = 0; c <= max_col; ++c) if (cnt[c]) avg += cnt[c];
+        avg_by_r[r] = avg / distinct;                                  // 0/0 -> nan, as the reference prints it
     }
+    if (dbg_h) fprintf(stderr, "[dg::haploid] per-r backtracks %.3f s\n", now_s() - th0);
     if (!opt.quiet)
-        for (size_t i = 0; i + 1 < occ_count_by_r.size(); ++i) {       // :104-113
-            float avg = 0;
-            for (const auto &c : occ_count_by_r[i]) avg += c.second;
-            avg = avg / occ_count_by_r[i].size();
-            std::cout << "Approximation ratio certificate: " << avg << std::endl;
-        }
+        for (int i = 0; i < R; ++i) std::cout << "Approximation ratio certificate: " << avg_by_r[i] << std::endl;
     int best_r = 0;                                                    // :116-136
     double max_delta = 0;
     for (size_t i = 0; i + 1 < colors_by_r.size(); ++i) {
