@@ -133,6 +133,77 @@ def reference_baseline(cache, workload, bench_gfa, device):
                       f"{cells} cells): its DP function took {dp_s:.2f} s of {wall:.1f} s end to end; FASTA md5 matches the golden"}
 
 
+def sketch_config4(cache, ctx, sk, dict_t, device, world, rank, backend, K, W, reps=5):
+    """BASELINE configs[3]: 30x reads (10^6 x 150 bp) on the same 24-walk panel, minimizer scoring sharded over the ranks
+    by read -- local HIP sketch, RCCL all-reduce of the dictionary hit vector, all-gather + device merge of the spectrum.
+    Untimed cross-check at N > 1: rank 0 sketches the whole set alone and must get the same spectrum and hit vector."""
+    import torch
+    import torch.distributed as dist
+    from dipgenie_amd import synth
+    from dipgenie_amd.dist_sketch import shard_bounds
+    if rank == 0:
+        path = synth.ensure_mhc24_reads(os.path.join(cache, "mhc24"))
+    if world > 1:
+        dist.barrier()
+    path = synth.ensure_mhc24_reads(os.path.join(cache, "mhc24"))
+    arr = np.load(path, mmap_mode="r")
+    n, rl = arr.shape
+
+    def resident(lo, hi):
+        b = torch.from_numpy(np.ascontiguousarray(arr[lo:hi]).reshape(-1)).to(device)
+        o = (torch.arange(hi - lo + 1, dtype=torch.int64) * rl).to(device)
+        return b, o
+    lo, hi = shard_bounds(n, world, rank)
+    bases_t, off_t = resident(lo, hi)
+
+    def one():
+        h, c = sk.local(bases_t, off_t, K, W)
+        counts = sk.dictionary_counts(dict_t, h, c)
+        gh, gc = sk.global_spectrum(h, c)
+        torch.cuda.synchronize()
+        return counts, gh, gc
+    counts, gh, gc = one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(reps):
+        counts, gh, gc = one()
+        tm = ctx.sketch_timing()
+        dev_ms += tm.total_ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el, dev_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, dev_ms = (float(x) for x in t.tolist())
+    if rank != 0:
+        return None
+    res = {"workload": f"{n} x {rl}-bp reads (30x, seed 30) on the bench panel, sharded by read over {world} rank(s)",
+           "reads": int(n), "passes": reps, "reads_per_s": n * reps / el, "Gbp_per_s": n * rl * reps / el / 1e9, "ms_per_pass": 1e3 * el / reps,
+           "local_sketch_ms_max_rank": dev_ms / reps, "distinct_hashes": int(gh.numel()), "dictionary_hits": int((counts > 0).sum().item()),
+           "collectives": "none (1 rank)" if world == 1 else f"{backend}: all-reduce int32[{int(dict_t.numel())}] + all-gather of (hash, count) runs"}
+    if world > 1:
+        fb, fo = resident(0, n)
+        h1, c1 = sk.local(fb, fo, K, W)
+        torch.cuda.synchronize()
+        same = bool(h1.numel() == gh.numel() and torch.equal(h1, gh) and torch.equal(c1, gc))
+        cnt1 = torch.zeros_like(counts)
+        from dipgenie_amd import capi
+        torch.cuda.synchronize()
+        capi._check(capi.lib.dg_sketch_count_dictionary_dev(ctx.h, dict_t.data_ptr(), dict_t.numel(), h1.data_ptr(), c1.data_ptr(), h1.numel(),
+                                                            cnt1.data_ptr()), "dg_sketch_count_dictionary_dev")
+        sk.ctx_sync()
+        same = same and torch.equal(cnt1, counts)
+        res["matches_single_rank"] = same
+        if not same:
+            raise SystemExit("sharded config-4 sketch differs from the single-rank sketch")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +215,7 @@ def main():
     ap.add_argument("--cpu-sample-cells", type=float, default=6e8)
     ap.add_argument("--no-concurrent", action="store_true", help="skip the multi-instance-per-GPU measurement")
     ap.add_argument("--no-reference-baseline", action="store_true", help="skip the oracle/_ref run (about 30 s)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 30x read-set sketch measurement (BASELINE configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -269,6 +341,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, sk_s, dp_s = (float(x) for x in t.tolist())
 
+    sk4 = None
+    if args.workload == "mhc24" and not args.no_config4:
+        sk4 = sketch_config4(args.cache, ctx, sk, dict_t, device, world, rank, backend, K, W)
+
     if rank == 0:
         if e2e is not None and out.value != e2e["dp_value"]:
             raise SystemExit(f"bench DP value {out.value} != CLI DP value {e2e['dp_value']}")
@@ -309,6 +385,8 @@ def main():
                 line["roofline"]["traffic_range"] = [pmc["hbm_bytes_per_launch"]["low"], pmc["hbm_bytes_per_launch"]["high"]]
                 line["roofline"]["traffic_source"] = ("profiles/r01_pmc_mhc24_traffic.json: WRITE_SIZE + calibrated FETCH_SIZE of all "
                                                       f"{n_launch} sweep launches of one DP pass on this workload (separate --pmc passes)")
+        if sk4 is not None:
+            line["sketch_config4"] = sk4
         if e2e is not None:
             line["end_to_end_s"] = e2e["wall_s"]
             line["end_to_end_stages_s"] = e2e.get("stages")

@@ -67,6 +67,50 @@ def simulate_reads(rng, haps, n_reads, read_len=150, sub_rate=0.002):
     return out
 
 
+def simulate_reads_array(rng, haps, n_reads, read_len=150, sub_rate=0.002):
+    """Vectorised simulator for large read sets (BASELINE configs[3]: 30x = 10^6 reads): uniform positions on the given
+    haplotypes (round-robin), substitutions at sub_rate, random strand.  Returns a uint8 array [n_reads, read_len].
+    Same recipe as simulate_reads but another random stream, so no golden depends on it."""
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+        comp[a] = b
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    code = np.zeros(256, np.uint8)
+    code[alpha] = np.arange(4, dtype=np.uint8)
+    out = np.empty((n_reads, read_len), np.uint8)
+    cols = np.arange(read_len, dtype=np.int64)
+    for hi, h in enumerate(haps):
+        rows = np.arange(hi, n_reads, len(haps))
+        ha = np.frombuffer(h, np.uint8)
+        pos = rng.integers(0, len(h) - read_len + 1, rows.size)
+        for b0 in range(0, rows.size, 1 << 16):                      # blocks keep the index matrix small
+            sl = slice(b0, min(b0 + (1 << 16), rows.size))
+            out[rows[sl]] = ha[pos[sl, None] + cols[None, :]]
+    nerr = int(rng.binomial(out.size, sub_rate))
+    flat = out.reshape(-1)
+    where = rng.integers(0, flat.size, nerr)
+    flat[where] = alpha[(code[flat[where]] + 1 + rng.integers(0, 3, nerr)) % 4]
+    flip = rng.integers(0, 2, n_reads).astype(bool)
+    out[flip] = comp[out[flip][:, ::-1]]
+    return out
+
+
+def ensure_mhc24_reads(cache_dir, coverage=30.0, seed=30, read_len=150, sample=(5, 6)):
+    """Config-4 read set for the panel of ensure_mhc24: `coverage`x reads from the same two mosaic walks. Returns the path
+    of a .npy uint8 matrix [n_reads, read_len] (memory-mapped by the ranks)."""
+    gfa, _, _ = ensure_mhc24(cache_dir)
+    path = os.path.join(cache_dir, "mhc24_%dx_seed%d.npy" % (int(coverage), seed))
+    if not os.path.exists(path):
+        _, seqs, _, walks = parse_gfa(gfa)
+        haps = [b"".join(seqs[v] for v in walks[h][2]).upper() for h in sample]
+        n_reads = int(coverage * sum(len(h) for h in haps) / 2 / read_len)
+        arr = simulate_reads_array(np.random.default_rng(seed), haps, n_reads, read_len)
+        tmp = path + ".tmp%d.npy" % os.getpid()
+        np.save(tmp, arr)
+        os.replace(tmp, path)
+    return path
+
+
 def random_bubble_graph(seed, n_bubbles=12, n_haps=4, seg_len=(20, 60), alleles=(2, 3), coverage=6.0,
                         read_len=80, sub_rate=0.0, sample_haps=(0, 1)):
     """A chain of bubbles: backbone segment, then `a` alternative allele segments, repeated.
