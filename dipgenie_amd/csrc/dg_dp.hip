@@ -37,6 +37,12 @@ constexpr int MAX_K = 1 << 15;                          // hop words pack positi
 // tie order); 0xFFFF = unreachable.  Only a level with an in-degree > 255 keeps the wide word
 // pred_i | pred_j << 15 | wu << 30 | wv << 31 (two 16-bit units per cell) and runs on the generic kernel.
 constexpr int BP_MAX_RANK = 255;
+#ifndef DG_HEAVY_U1
+#define DG_HEAVY_U1 8                                    // in-edges per step of a heavy row at RC = 1 / RC = 2
+#endif
+#ifndef DG_HEAVY_U2
+#define DG_HEAVY_U2 8
+#endif
 
 struct LevelDesc {                                      // transition (l-1) -> l, indexed by l
     int32_t a0, k;                                      // source level: first vertex id, width
@@ -472,18 +478,20 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         // heavy rows (recombination fan-in): U in-edges per step -- all their loads (U deltas + U*RC values) go out
         // back to back, then the selects run; (value, ord) max is associative and commutative, so the order inside
         // a step is irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
-        constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : 8);
+        constexpr int U = RC >= 8 ? 2 : (RC >= 4 ? 4 : (RC >= 3 ? 8 : (RC == 2 ? DG_HEAVY_U2 : DG_HEAVY_U1)));
         const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;
         for (int t = t_lo; t < t_hi; t += U) {
-            uint32_t pu[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) pu[u] = (uint32_t)__builtin_amdgcn_readlane((int)mypu, min(t + u, t_hi - 1));
+            // the in-edge words live in SGPRs only until the load offset is formed; the select needs just their weight
+            // bits, kept in one mask (a deep step would otherwise hold U scalars and spill)
+            uint32_t wmask = 0;
             if (act) {
                 int vals[U][RC], dl[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (t + u < t_hi) {                                   // wave-uniform
-                        const int iu = (int)(pu[u] & 0x7FFFFFFFu), w = (int)(pu[u] >> 31) + wv;
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mypu, t + u);
+                        wmask |= (p >> 31) << u;
+                        const int iu = (int)(p & 0x7FFFFFFFu), w = (int)(p >> 31) + wv;
                         const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
                         dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
 #pragma unroll
@@ -493,7 +501,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (t + u < t_hi) {
-                        const int wu = (int)(pu[u] >> 31);
+                        const int wu = (int)((wmask >> u) & 1u);
                         relax_select<RC>(vals[u], dl[u], ord_rank(t + u, evr), r0, wu + wv, RP, bval, bord);
                     }
                 }

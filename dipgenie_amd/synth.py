@@ -95,6 +95,25 @@ def simulate_reads_array(rng, haps, n_reads, read_len=150, sub_rate=0.002):
     return out
 
 
+def ensure_mhc4_hg002(cache_dir, base_gfa=None, seed=1, coverage=2.0, read_len=150, sub_rate=0.002, walks=("HG002",)):
+    """BASELINE configs[1] stand-in for the missing test/HG002.mhc.2x.fq.gz: 2x reads (1x from each of
+    the two HG002 walks of MHC_4.gfa.gz), seeded. Returns (gfa_path, reads_path)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base_gfa = base_gfa or os.path.join(root, "tests", "data", "MHC_4.gfa.gz")
+    os.makedirs(cache_dir, exist_ok=True)
+    reads = os.path.join(cache_dir, "mhc4_hg002_2x_seed%d.fa" % seed)
+    if not os.path.exists(reads):
+        _, seqs, _, wl = parse_gfa(base_gfa)
+        haps = [b"".join(seqs[v] for v in w).upper() for (name, _, w) in wl if name in walks]
+        assert len(haps) == 2, [n for (n, _, _) in wl]
+        n_reads = int(coverage * sum(len(h) for h in haps) / 2 / read_len)
+        rd = simulate_reads(np.random.default_rng(seed), haps, n_reads, read_len, sub_rate)
+        tmp = reads + ".tmp%d" % os.getpid()
+        write_fasta(tmp, rd)
+        os.replace(tmp, reads)
+    return base_gfa, reads
+
+
 def ensure_mhc24_reads(cache_dir, coverage=30.0, seed=30, read_len=150, sample=(5, 6)):
     """Config-4 read set for the panel of ensure_mhc24: `coverage`x reads from the same two mosaic walks. Returns the path
     of a .npy uint8 matrix [n_reads, read_len] (memory-mapped by the ranks)."""

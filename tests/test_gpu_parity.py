@@ -185,6 +185,24 @@ def test_dp_delta_windows(gpu_ctx, cap, seg):
         gpu_ctx.dp_set_option("segment_cells", 0)
 
 
+@pytest.mark.parametrize("ahead,cap,seg", [(0, 0, 0), (1, 0, 0), (7, 0, 0), (7, 400, 0), (3, 400, 5000), (1000, 0, 5000)])
+def test_dp_sweep_lookahead(gpu_ctx, ahead, cap, seg):
+    """the sweep streams the graph tables of the next batch of levels through the Infinity Cache (reads only): any batch
+    size, with delta windows and lattice segments cutting the ranges, leaves every result and level digest unchanged"""
+    try:
+        gpu_ctx.dp_set_option("warm_ahead", ahead)
+        gpu_ctx.dp_set_option("delta_cap_entries", cap)
+        gpu_ctx.dp_set_option("segment_cells", seg)
+        for seed, kw in [(41, dict(max_width=14, n_levels=300, R=6, p_colour=0.6)), (42, dict(max_width=45, n_levels=60, R=18, p_w1=0.5, p_colour=0.9)),
+                         (43, dict(n_levels=2, R=2)), (44, dict(max_width=8, n_levels=2000, R=3, p_colour=0.3))]:
+            _dp_both(gpu_ctx, graphgen.random_levelized(8300 + seed, **kw))
+        _dp_both(gpu_ctx, capi.DpGraphArrays.load(os.path.join(HERE, "golden", "toy1_k5w3_R2.dpg")))
+    finally:
+        gpu_ctx.dp_set_option("warm_ahead", 128)
+        gpu_ctx.dp_set_option("delta_cap_entries", 0)
+        gpu_ctx.dp_set_option("segment_cells", 0)
+
+
 @pytest.mark.parametrize("chunk_cells", [1, 3000, 150000])
 def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
     """the resident back-pointer lattice is a pool of chunks mapped by a background thread while the sweep runs;
@@ -331,6 +349,18 @@ def test_cli_e2e_mhc24_synthetic(built_hip, gpu_ctx, tmp_path):
     fa, summ = _run_cli(built_hip, case, tmp_path)
     assert hashlib.md5(fa).hexdigest() == c["fasta_md5"] == "cd13930ac90651b7e441506c1ecd4514"
     assert (summ["dp_value"], summ["r1"], summ["r2"]) == (331848, 10, 8)
+
+
+def test_cli_e2e_mhc4_hg002_2x(built_hip, gpu_ctx, tmp_path):
+    """BASELINE config 2 with diploid reads: seeded 2x reads from the two HG002 walks stand in for the missing
+    test/HG002.mhc.2x.fq.gz; golden = the reference binary on the same files"""
+    c = CASES["mhc4_hg002_2x"]
+    gfa, reads = synth.ensure_mhc4_hg002(str(tmp_path / "hg002"))
+    assert hashlib.md5(open(reads, "rb").read()).hexdigest() == c["reads_md5"]
+    case = dict(c, gfa=os.path.relpath(gfa, ROOT), reads=os.path.relpath(reads, ROOT))
+    fa, summ = _run_cli(built_hip, case, tmp_path)
+    assert hashlib.md5(fa).hexdigest() == c["fasta_md5"] == "b56e7ea82ccd32ce24ec641a677c4c7e"
+    assert (summ["dp_value"], summ["r1"], summ["r2"], summ["spectrum"]) == (181090, 9, 9, 387040)
 
 
 def test_cli_e2e_mhc4_haploid(built_hip, gpu_ctx, tmp_path):
