@@ -46,3 +46,27 @@ def test_product_does_not_link_oracle(built_hip):
         assert "oracle" not in out
         sym = subprocess.run(["nm", "-D", f], stdout=subprocess.PIPE).stdout.decode()
         assert "orc_" not in sym
+
+
+def test_cli_usage_and_exit_codes(built_hip, tmp_path):
+    """process surface (main.cpp:90-110): a missing -g / -r / -o prints the usage on stderr and exits 1, nothing on stdout"""
+    import subprocess
+    for args in ([], ["-g", "x.gfa"], ["-g", "x.gfa", "-r", "y.fa"], ["-r", "y.fa", "-o", "z.fa"]):
+        p = subprocess.run([built_hip, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=tmp_path)
+        assert p.returncode == 1, args
+        assert p.stdout == b"" and p.stderr.startswith(b"Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta>")
+        for flag in (b"-k INT", b"-w INT", b"-R INT", b"-t INT", b"-p INT", b"-T FLOAT"):
+            assert flag in p.stderr, flag
+
+
+def test_cli_fails_loudly_without_gpu(built_hip, tmp_path):
+    """the product CLI has no CPU path: on a machine without a gfx950 device it must stop with an error, not fall back"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = tmp_path / "o.fa"
+    p = subprocess.run([built_hip, "-p2", "-R2", "-k5", "-w3", "-g", os.path.join(ROOT, "tests", "data", "test.gfa"),
+                        "-r", os.path.join(ROOT, "tests", "data", "read.fa"), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"no CPU fallback" in p.stderr
+    assert not out.exists() or out.stat().st_size == 0
