@@ -1,0 +1,129 @@
+// What a chain of dependent per-level launches costs on this device, piece by piece -- the floor under the DP sweep
+// (one launch per graph level, every level reads what the previous launch wrote).  Each variant issues N launches
+// back to back on one stream and reports microseconds per launch (HIP events around the whole chain):
+//   empty1      1 workgroup, empty body, 80-byte by-value argument block (the sweep passes its LevelDesc that way)
+//   emptyG      G workgroups of 256 threads, empty body                     (wave dispatch of a typical level)
+//   round1      G workgroups; every wave: load a record, store a value      (one memory round + store)
+//   round2      ... load a record, then the value of the previous launch at the index found there, store  (two dependent rounds:
+//               the sweep's common task -- row/slot record, then state values)
+//   round2cold  round2, the records of every launch come from a fresh region (HBM misses, like the sweep's tables)
+//   round3..5   more dependent rounds (rows with 9-24 in-edges walk them in steps of eight)
+//   hipcc --offload-arch=gfx950 -O2 tools/level_floor.hip -o bin/level_floor && bin/level_floor [N] [G]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+struct Desc { int32_t w[20]; };                                     // 80 bytes, by value
+
+__global__ __launch_bounds__(256) void k_empty(Desc d) { if (d.w[0] == 0x7fffffff) __builtin_trap(); }
+
+// ROUNDS dependent loads: rec[] holds indices into the state; after the first record load every further round loads the
+// state word at the index obtained in the previous round (the state of the previous launch), then one store.
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_rounds(Desc d, const uint32_t *__restrict__ rec, const uint32_t *__restrict__ cur, uint32_t *__restrict__ nxt, uint32_t mask) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t x = rec[(size_t)d.w[1] + t];                          // round 1: record (table read, never written)
+#pragma unroll
+    for (int r = 1; r < ROUNDS; ++r) x = cur[(x + t) & mask] + (uint32_t)r;   // rounds 2..: values written by the previous launch
+    nxt[t & mask] = x & mask;
+}
+
+// Persistent alternative: one resident grid loops over the levels; hand-off = agent-scope release of this workgroup's
+// stores, one atomic counter, agent-scope (cache-bypassing) loads of the state.  Spins are bounded: a workgroup that waits
+// too long raises `abort` and every workgroup leaves.
+struct Ctl { uint32_t count, abort, pad[14]; };
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_persist(int n_iter, const uint32_t *__restrict__ rec, uint32_t *s0, uint32_t *s1, uint32_t mask, Ctl *ctl, int cold_stride) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    for (int it = 0; it < n_iter; ++it) {
+        const uint32_t *cur = (it & 1) ? s1 : s0;
+        uint32_t *nxt = (it & 1) ? s0 : s1;
+        uint32_t x = rec[(size_t)(it & 4095) * cold_stride + t];
+#pragma unroll
+        for (int r = 1; r < ROUNDS; ++r) x = __hip_atomic_load(&cur[(x + t) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint32_t)r;
+        __hip_atomic_store(&nxt[t & mask], x & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                            // (compiler waits for this wave's stores before the barrier)
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&ctl->count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = gridDim.x * (uint32_t)(it + 1);
+            uint32_t spin = 0;
+            while (__hip_atomic_load(&ctl->count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (++spin > (1u << 20) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 20000;
+    const int G = argc > 2 ? atoi(argv[2]) : 1024;                  // workgroups per launch (MHC-24 levels: 800-2200)
+    const uint32_t words = 1u << 18, mask = words - 1;              // 1 MB of state, like an average MHC-24 level
+    CK(hipSetDevice(0));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    uint32_t *rec, *st[2];
+    const size_t rec_words = (size_t)G * 256 * 4096;                // "cold": 4096 distinct record regions, cycled
+    CK(hipMalloc(&rec, rec_words * 4)); CK(hipMalloc(&st[0], words * 4)); CK(hipMalloc(&st[1], words * 4));
+    {
+        std::vector<uint32_t> h((size_t)G * 256);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u) & mask;
+        for (size_t o = 0; o < rec_words; o += h.size()) CK(hipMemcpy(rec + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(st[0], 0, words * 4)); CK(hipMemset(st[1], 0, words * 4));
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char *name, auto launch) -> int {
+        for (int rep = 0; rep < 2; ++rep) {                         // first repetition warms clocks and code
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < N; ++i) launch(i);
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("%-11s %7.3f us/launch  (%d launches, %d workgroups)\n", name, 1e3 * ms / N, N, G);
+        }
+        return 0;
+    };
+    Desc d{};
+    if (run("empty1", [&](int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, s, d); })) return 1;
+    if (run("emptyG", [&](int) { hipLaunchKernelGGL(k_empty, dim3(G), dim3(256), 0, s, d); })) return 1;
+#define ROUND(NAME, R, COLD) if (run(NAME, [&](int i) { Desc q = d; q.w[1] = (COLD) ? (int)((size_t)(i & 4095) * G * 256) : 0; \
+        hipLaunchKernelGGL((k_rounds<R>), dim3(G), dim3(256), 0, s, q, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1
+    ROUND("round1", 1, 0);
+    ROUND("round2", 2, 0);
+    ROUND("round2cold", 2, 1);
+    ROUND("round3", 3, 0);
+    ROUND("round4", 4, 0);
+    ROUND("round5", 5, 0);
+    ROUND("round5cold", 5, 1);
+    // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
+    Ctl *ctl; CK(hipMalloc(&ctl, sizeof(Ctl)));
+    int dev_cus = 0; CK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, 0));
+    for (int PG : {dev_cus / 8, dev_cus, 2 * dev_cus}) {
+        for (int rounds : {2, 5}) {
+            for (int cold = 0; cold < 2; ++cold) {
+                float best = 1e30f; uint32_t aborted = 0;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CK(hipMemsetAsync(ctl, 0, sizeof(Ctl), s));
+                    CK(hipEventRecord(e0, s));
+                    if (rounds == 2) hipLaunchKernelGGL((k_persist<2>), dim3(PG), dim3(256), 0, s, N, rec, st[0], st[1], mask, ctl, cold ? PG * 256 : 0);
+                    else hipLaunchKernelGGL((k_persist<5>), dim3(PG), dim3(256), 0, s, N, rec, st[0], st[1], mask, ctl, cold ? PG * 256 : 0);
+                    CK(hipEventRecord(e1, s));
+                    CK(hipStreamSynchronize(s));
+                    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+                    Ctl h; CK(hipMemcpy(&h, ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+                    aborted |= h.abort;
+                    if (ms < best) best = ms;
+                }
+                printf("persist%d%s %7.3f us/level   (%d levels, %d resident workgroups)%s\n", rounds, cold ? "cold" : "    ", 1e3 * best / N, N, PG,
+                       aborted ? "  ABORTED (barrier timeout)" : "");
+            }
+        }
+    }
+    return 0;
+}
