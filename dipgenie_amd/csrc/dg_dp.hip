@@ -22,8 +22,10 @@
 #include <cstring>
 #include <ctime>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 
 #include "dg_internal.hpp"
 
@@ -81,6 +83,8 @@ struct DpState {
     int64_t coop_cost_ns = 0;                           // model: barrier + LDS merge of a cooperative task
     int64_t use_coop = 1;                               // option: cooperative tasks for rows with many in-edges
     int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
+    int64_t graph_batch = -1;                           // option: levels per captured hipGraph (0 = plain launches, -1 = by level width)
+    std::map<std::tuple<int, int, const void *>, hipGraphExec_t> graphs;   // (first level, end level, biased lattice pointer) -> replayable batch
     int64_t warm_ahead = 128;                           // option: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // option: drain the stream every N level launches (profiler aid)
     struct Segment { int begin, end; bool team; };
@@ -124,8 +128,14 @@ struct DpState {
     int seg_chunks = 1;                        // chunks per lattice segment (= all of them when the lattice is resident)
 };
 
+static void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
+    for (auto &kv : S.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    S.graphs.clear();
+}
+
 void dp_state_free(DpState *s) {
     if (!s) return;
+    graphs_clear(*s);
     { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
     if (s->pool.th.joinable()) s->pool.th.join();
     for (void *q : s->pool.chunks) (void)hipFree(q);
@@ -1253,6 +1263,7 @@ static int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (g->level_off[1] != 1) { set_error("level 0 must hold exactly the source vertex"); return DG_ERR_ARG; }
     if (!c->dp) c->dp = new DpState();
     DpState &S = *c->dp;
+    graphs_clear(S);
     S.loaded = false;
     S.nV = nV; S.L = L; S.R = R; S.RP = R + 1;
     // Host-side table construction runs on a few std::threads over contiguous LEVEL ranges balanced by vertex count
@@ -1731,6 +1742,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     F.pad_bytes = (int)(4 * S.pad_front);
     F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
     int64_t n_launch = 0;
+    double host_enqueue_s = 0;                          // host time spent issuing the sweep's launches (DG_DEBUG)
     uint32_t team_err = 0;
     bool team_used = false, team_failed = false;
     int n_team_launch = 0;
@@ -1814,82 +1826,105 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                 }
                 continue;
             }
-            for (int l = seg.begin; l < seg.end; ++l) {
-                LevelDesc &d = S.descs[l];
-                if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
-                if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0) {
-                    // tables of the batch after this one (and, at the start of a range, of this one too)
-                    const int q0 = l == lb ? l : (int)std::min<int64_t>(l + S.warm_ahead, le), q1 = (int)std::min<int64_t>(l + 2 * S.warm_ahead, le);
-                    if (q1 > q0) warm_tables(q0, q1);
+            // Issuing a level costs the host 3-4.5 us (hipLaunchKernelGGL), the GPU 2-3 us on narrow levels: batches of levels are
+            // captured once into hipGraphs and replayed on later passes over the same resident graph (option graph_batch).
+            // Measured: MHC_4 (3.5 k cells per level) 390 -> 358 ms per sweep, also on the capturing pass; MHC-24 (265 k cells per
+            // level, GPU-bound at 4.6 us) 651 -> 658 ms.  -1 picks 1,000-level batches for graphs below 32 k cells per level.
+            const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : ((int64_t)(S.cells / (uint64_t)std::max(S.L, 1)) < 32768 ? 1000 : 0);
+            const bool use_graph = gb > 0 && n_win == 1 && S.sync_every == 0;
+            for (int l0 = seg.begin; l0 < seg.end;) {
+                const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, seg.end) : seg.end;
+                hipGraphExec_t *slot = nullptr;
+                if (use_graph) {
+                    slot = &S.graphs[std::make_tuple(l0, l1, (const void *)bp_biased)];
+                    if (*slot) { DG_HIP(hipGraphLaunch(*slot, s)); n_launch += l1 - l0; l0 = l1; continue; }
+                    DG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 }
-                // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
-                // non-temporal ones that keep the once-written lattice out of the L2
-                d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
-                if (d.fast_ok && small_state && S.RP <= 65535 && S.use_fast) {
-                    // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
-                    // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
-                    const int64_t base = (int64_t)d.k2 * d.nblocks;
-                    int rc = rc_sel;
-                    bool coop = false;
-                    if (S.adaptive_rc == 1) {                             // first rule: smallest RC whose waves fit a budget
-                        static const int cand[5] = {1, 2, 4, 8, 16};
-                        for (int q = 0; q < 5; ++q)
-                            if (cand[q] < rc_sel && base * ((S.RP + cand[q] - 1) / cand[q]) <= S.chip_waves) { rc = cand[q]; break; }
-                    } else if (S.adaptive_rc >= 2) {
-                        // Cost model fitted on MHC-24 (R = 18) and the 100-walk chr22-style panel (R = 32):
-                        //   T(RC) = max(1, W / cap) * (t0 + dmax * RC * tg) + W * tw,   W = tasks * ceil(RP / RC) waves.
-                        // First factor: rounds of resident waves; second: a wave's dependent chain (the row with the
-                        // largest in-degree walks dmax in-edges with RC gathers each); last: per-wave issue overhead.
-                        // Cooperative variant (RC <= 4, lean levels): rows above COOP_MIN in-edges are walked by four waves, so
-                        // the chain is a quarter (at least COOP_MIN) while four extra workgroup slots per heavy row are launched.
-                        const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
-                        const bool coop_ok = S.use_coop && S.adaptive_rc >= 3 && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
-                        const double dmax = (double)std::max(1, S.level_dmax[l]);
-                        double best = 1e300;
-                        for (int pass = (coop_ok && S.use_coop == 2) ? 1 : 0; pass < (coop_ok ? 2 : 1); ++pass) {     // coop = 2 (tests): whenever possible
-                            for (int q = 0; q < 11; ++q) {
-                                if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
-                                if (S.adaptive_rc == 2 && (cand[q] == 3 || cand[q] == 5 || cand[q] == 6 || cand[q] == 10 || cand[q] == 11)) continue;   // 3: all sizes
-                                if (pass == 1 && cand[q] > 4) continue;
-                                const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
-                                const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
-                                const double W = rows * d.nblocks * ((S.RP + cand[q] - 1) / cand[q]);
-                                const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + (pass ? (double)S.coop_cost_ns : 0.0) + chain * cand[q] * (double)S.rc_tg_ps * 1e-3) +
-                                                 W * (double)S.rc_tw_ps * 1e-3;
-                                if (T <= best) { best = T; rc = cand[q]; coop = pass == 1; }   // ties: the larger RC (fewer waves)
+                for (int l = l0; l < l1; ++l) {
+                    LevelDesc &d = S.descs[l];
+                    if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
+                    if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0) {
+                        // tables of the batch after this one (and, at the start of a range, of this one too)
+                        const int q0 = l == lb ? l : (int)std::min<int64_t>(l + S.warm_ahead, le), q1 = (int)std::min<int64_t>(l + 2 * S.warm_ahead, le);
+                        if (q1 > q0) warm_tables(q0, q1);
+                    }
+                    // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
+                    // non-temporal ones that keep the once-written lattice out of the L2
+                    d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
+                    if (d.fast_ok && small_state && S.RP <= 65535 && S.use_fast) {
+                        // A lone wave retires ~1 instruction per 4-8 cycles, so the RC-fold unrolled task is the level's
+                        // critical path: while the chip has idle wave slots, give each wave fewer recombination counts.
+                        const int64_t base = (int64_t)d.k2 * d.nblocks;
+                        int rc = rc_sel;
+                        bool coop = false;
+                        if (S.adaptive_rc == 1) {                             // first rule: smallest RC whose waves fit a budget
+                            static const int cand[5] = {1, 2, 4, 8, 16};
+                            for (int q = 0; q < 5; ++q)
+                                if (cand[q] < rc_sel && base * ((S.RP + cand[q] - 1) / cand[q]) <= S.chip_waves) { rc = cand[q]; break; }
+                        } else if (S.adaptive_rc >= 2) {
+                            // Cost model fitted on MHC-24 (R = 18) and the 100-walk chr22-style panel (R = 32):
+                            //   T(RC) = max(1, W / cap) * (t0 + dmax * RC * tg) + W * tw,   W = tasks * ceil(RP / RC) waves.
+                            // First factor: rounds of resident waves; second: a wave's dependent chain (the row with the
+                            // largest in-degree walks dmax in-edges with RC gathers each); last: per-wave issue overhead.
+                            // Cooperative variant (RC <= 4, lean levels): rows above COOP_MIN in-edges are walked by four waves, so
+                            // the chain is a quarter (at least COOP_MIN) while four extra workgroup slots per heavy row are launched.
+                            const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
+                            const bool coop_ok = S.use_coop && S.adaptive_rc >= 3 && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
+                            const double dmax = (double)std::max(1, S.level_dmax[l]);
+                            double best = 1e300;
+                            for (int pass = (coop_ok && S.use_coop == 2) ? 1 : 0; pass < (coop_ok ? 2 : 1); ++pass) {     // coop = 2 (tests): whenever possible
+                                for (int q = 0; q < 11; ++q) {
+                                    if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
+                                    if (S.adaptive_rc == 2 && (cand[q] == 3 || cand[q] == 5 || cand[q] == 6 || cand[q] == 10 || cand[q] == 11)) continue;   // 3: all sizes
+                                    if (pass == 1 && cand[q] > 4) continue;
+                                    const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
+                                    const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
+                                    const double W = rows * d.nblocks * ((S.RP + cand[q] - 1) / cand[q]);
+                                    const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + (pass ? (double)S.coop_cost_ns : 0.0) + chain * cand[q] * (double)S.rc_tg_ps * 1e-3) +
+                                                     W * (double)S.rc_tw_ps * 1e-3;
+                                    if (T <= best) { best = T; rc = cand[q]; coop = pass == 1; }   // ties: the larger RC (fewer waves)
+                                }
                             }
                         }
+                        const int nch = (S.RP + rc - 1) / rc;
+                        const int wpb = coop ? 4 : (int)S.waves_per_block;    // waves (= slot blocks) per workgroup
+                        const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
+                        const int32_t *hv = S.d_heavy.as<int32_t>();
+    #define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); \
+                                  else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); } while (0)
+    #define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
+                                  else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
+    #define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
+                                                        default: DG_COOP(4, DG); break; } break; } \
+                                switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
+                                            case 4: DG_FAST(4, DG); break; case 5: DG_FAST(5, DG); break; case 6: DG_FAST(6, DG); break; \
+                                            case 8: DG_FAST(8, DG); break; case 10: DG_FAST(10, DG); break; case 11: DG_FAST(11, DG); break; \
+                                            case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
+                                            default: DG_FAST(33, DG); break; } } while (0)
+                        if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
+    #undef DG_COOP
+    #undef DG_FAST_RC
+    #undef DG_FAST
+                    } else {
+                        const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
+                        const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
+    #define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
+                        if (S.want_digest) { if (rc_sel == 8) DG_SWEEP(8, true); else if (rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
+                        else { if (rc_sel == 8) DG_SWEEP(8, false); else if (rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
+    #undef DG_SWEEP
                     }
-                    const int nch = (S.RP + rc - 1) / rc;
-                    const int wpb = coop ? 4 : (int)S.waves_per_block;    // waves (= slot blocks) per workgroup
-                    const dim3 grid((unsigned)((d.nblocks + wpb - 1) / wpb), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
-                    const int32_t *hv = S.d_heavy.as<int32_t>();
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(64 * wpb), 0, s, F, d, l, hv); } while (0)
-#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
-#define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
-                                                    default: DG_COOP(4, DG); break; } break; } \
-                            switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
-                                        case 4: DG_FAST(4, DG); break; case 5: DG_FAST(5, DG); break; case 6: DG_FAST(6, DG); break; \
-                                        case 8: DG_FAST(8, DG); break; case 10: DG_FAST(10, DG); break; case 11: DG_FAST(11, DG); break; \
-                                        case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
-                                        default: DG_FAST(33, DG); break; } } while (0)
-                    if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
-#undef DG_COOP
-#undef DG_FAST_RC
-#undef DG_FAST
-                } else {
-                    const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
-                    const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
-#define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
-                    if (S.want_digest) { if (rc_sel == 8) DG_SWEEP(8, true); else if (rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
-                    else { if (rc_sel == 8) DG_SWEEP(8, false); else if (rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
-#undef DG_SWEEP
+                    ++n_launch;
+                    // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
+                    if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
                 }
-                ++n_launch;
-                // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
-                if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
+                if (use_graph) {
+                    hipGraph_t cg = nullptr;
+                    DG_HIP(hipStreamEndCapture(s, &cg));
+                    DG_HIP(hipGraphInstantiate(slot, cg, nullptr, nullptr, 0));
+                    DG_HIP(hipGraphDestroy(cg));
+                    DG_HIP(hipGraphLaunch(*slot, s));
+                }
+                l0 = l1;
             }
         }
         return DG_OK;
@@ -1926,7 +1961,9 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
             const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
             uint16_t *base = S.d_bp.p ? S.d_bp.as<uint16_t>() : pool_base[ch - c0];
             biased[ch - c0] = base - S.descs[lb].bp_off;
+            const double th0 = wall_s();
             if (int rc = sweep_range(lb, le, biased[ch - c0])) return rc;
+            host_enqueue_s += wall_s() - th0;
         }
         if (mark_forward_end) DG_HIP(hipEventRecord(S.ev[2], s));
         for (int ch = c1 - 1; ch >= c0; --ch) {
@@ -2000,6 +2037,7 @@ retry_forward:
         goto retry_forward;
     }
     S.last_team_size = team_used ? (int)ctl_host[0].team_count[(ctl_host[0].leader_xcc_plus1 - 1) & 7] : 0;
+    if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)n_launch, 1e3 * host_enqueue_s, 1e6 * host_enqueue_s / (double)std::max<int64_t>(n_launch, 1));
     if (team_used && getenv("DG_DEBUG"))
         fprintf(stderr, "[dipgenie_hip] %d team launches; team size %d of %u WGs; first team: %.3f ms, shader clock %.0f MHz\n", n_team_launch,
                 S.last_team_size, ctl_host[0].registered, ctl_host[0].t_real / 1e5, ctl_host[0].t_real ? 100.0 * ctl_host[0].t_cycles / ctl_host[0].t_real : 0.0);
@@ -2074,6 +2112,7 @@ extern "C" int dg_dp_get_level_digest(dg_ctx *c, uint64_t *out, int64_t n) {
 extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     if (!c || !key) { dgi::set_error("dg_dp_set_option: null"); return DG_ERR_ARG; }
     if (!c->dp) c->dp = new dgi::DpState();
+    dgi::graphs_clear(*c->dp);
     if (!strcmp(key, "digest")) c->dp->want_digest = v;
     else if (!strcmp(key, "fast")) c->dp->use_fast = v;
     else if (!strcmp(key, "team")) c->dp->use_team = v;
@@ -2092,6 +2131,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     else if (!strcmp(key, "rc_tg_ps")) c->dp->rc_tg_ps = v;
     else if (!strcmp(key, "rc_tw_ps")) c->dp->rc_tw_ps = v;
     else if (!strcmp(key, "warm_rows")) c->dp->warm_rows = v;
+    else if (!strcmp(key, "graph_batch")) c->dp->graph_batch = v < -1 ? -1 : v;
     else if (!strcmp(key, "warm_ahead")) c->dp->warm_ahead = v < 0 ? 0 : v;
     else if (!strcmp(key, "bp_nt_min_cells")) c->dp->bp_nt_min_cells = v;
     else if (!strcmp(key, "host_threads")) c->dp->host_threads = v < 1 ? 1 : v;

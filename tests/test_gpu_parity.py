@@ -203,6 +203,30 @@ def test_dp_sweep_lookahead(gpu_ctx, ahead, cap, seg):
         gpu_ctx.dp_set_option("segment_cells", 0)
 
 
+@pytest.mark.parametrize("batch,seg,chunk", [(0, 0, 0), (1, 0, 0), (7, 0, 0), (1000, 0, 0), (7, 5000, 0), (5, 0, 3000)])
+def test_dp_graph_batches(gpu_ctx, batch, seg, chunk):
+    """level launches captured into hipGraphs and replayed: the capturing pass and the replaying passes give the oracle's
+    answer and level digests, also with lattice segments / pool chunks cutting the batches, and after another graph was
+    loaded into the same context (stale batches must not survive)"""
+    try:
+        gpu_ctx.dp_set_option("segment_cells", seg)
+        if chunk:
+            gpu_ctx.dp_set_option("lattice_chunk_cells", chunk)
+        gpu_ctx.dp_set_option("graph_batch", batch)
+        for seed, kw in [(51, dict(max_width=14, n_levels=300, R=6, p_colour=0.6)), (52, dict(max_width=45, n_levels=60, R=18, p_w1=0.5, p_colour=0.9)),
+                         (53, dict(n_levels=2, R=2)), (54, dict(max_width=8, n_levels=2000, R=3, p_colour=0.3))]:
+            g = graphgen.random_levelized(8400 + seed, **kw)
+            _dp_both(gpu_ctx, g)
+            first = gpu_ctx.dp_run()
+            for _ in range(2):                                  # replays of the cached batches
+                assert gpu_ctx.dp_run().key() == first.key()
+    finally:
+        gpu_ctx.dp_set_option("graph_batch", -1)
+        gpu_ctx.dp_set_option("segment_cells", 0)
+        if chunk:
+            gpu_ctx.dp_set_option("lattice_chunk_cells", 1 << 31)
+
+
 @pytest.mark.parametrize("chunk_cells", [1, 3000, 150000])
 def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
     """the resident back-pointer lattice is a pool of chunks mapped by a background thread while the sweep runs;

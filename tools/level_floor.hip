@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void k_rounds(Desc d, const uint32_t *__restri
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     uint32_t x = rec[(size_t)d.w[1] + t];                          // round 1: record (table read, never written)
 #pragma unroll
-    for (int r = 1; r < ROUNDS; ++r) x = cur[(x + t) & mask] + (uint32_t)r;   // rounds 2..: values written by the previous launch
-    nxt[t & mask] = x & mask;
+    for (int r = 1; r < ROUNDS; ++r) x = cur[(x + (uint32_t)r * 64u) & mask];   // rounds 2..: values written by the previous launch (coalesced: a wave reads 64 consecutive words)
+    nxt[t & mask] = (x + 4096u) & mask;                            // keeps lanes consecutive: x = wave base + lane throughout
 }
 
 // Persistent alternative: one resident grid loops over the levels; hand-off = agent-scope release of this workgroup's
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void k_persist(int n_iter, const uint32_t *__r
         uint32_t *nxt = (it & 1) ? s0 : s1;
         uint32_t x = rec[(size_t)(it & 4095) * cold_stride + t];
 #pragma unroll
-        for (int r = 1; r < ROUNDS; ++r) x = __hip_atomic_load(&cur[(x + t) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint32_t)r;
-        __hip_atomic_store(&nxt[t & mask], x & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 1; r < ROUNDS; ++r) x = __hip_atomic_load(&cur[(x + (uint32_t)r * 64u) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&nxt[t & mask], (x + 4096u) & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                            // (compiler waits for this wave's stores before the barrier)
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(&ctl->count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -73,9 +73,9 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&rec, rec_words * 4)); CK(hipMalloc(&st[0], words * 4)); CK(hipMalloc(&st[1], words * 4));
     {
         std::vector<uint32_t> h((size_t)G * 256);
-        for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)(i * 2654435761u) & mask;
+        for (size_t i = 0; i < h.size(); ++i) h[i] = ((((uint32_t)(i >> 6) * 2654435761u) & mask & ~63u) | (uint32_t)(i & 63));   // wave base + lane
         for (size_t o = 0; o < rec_words; o += h.size()) CK(hipMemcpy(rec + o, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMemset(st[0], 0, words * 4)); CK(hipMemset(st[1], 0, words * 4));
+        { std::vector<uint32_t> z(words); for (uint32_t i = 0; i < words; ++i) z[i] = i; CK(hipMemcpy(st[0], z.data(), words * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(st[1], z.data(), words * 4, hipMemcpyHostToDevice)); }
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char *name, auto launch) -> int {
@@ -101,6 +101,35 @@ int main(int argc, char **argv) {
     ROUND("round4", 4, 0);
     ROUND("round5", 5, 0);
     ROUND("round5cold", 5, 1);
+    // the same chains replayed from a hipGraph (2,000 kernel nodes captured once, launched 10 times): no per-launch host work
+    auto graph = [&](const char *name, auto launch) -> int {
+        const int M = 2000;
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < M; ++i) launch(i);
+        CK(hipStreamEndCapture(s, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+        CK(hipEventRecord(e0, s));
+        for (int r = 0; r < 10; ++r) CK(hipGraphLaunch(ge, s));
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("graph %-11s %7.3f us/node   (10 x %d nodes)\n", name, 1e3 * ms / (10.0 * M), M);
+        CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        return 0;
+    };
+    if (graph("empty1", [&](int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, s, d); })) return 1;
+    if (graph("emptyG", [&](int) { hipLaunchKernelGGL(k_empty, dim3(G), dim3(256), 0, s, d); })) return 1;
+    if (graph("round2", [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(G), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
+    if (graph("round5", [&](int i) { hipLaunchKernelGGL((k_rounds<5>), dim3(G), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
+    for (int g2 : {16, 64, 256, 512, 2048, 4096}) {
+        char nm[32]; snprintf(nm, sizeof nm, "round2/%dwg", g2);
+        if (g2 > G && g2 * 256 > (int)(rec_words / 4096)) continue;
+        if (graph(nm, [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(g2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
+        if (run(nm, [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(g2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
+    }
+    if (argc > 3) return 0;                                         // any third argument: skip the persistent variants
     // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
     Ctl *ctl; CK(hipMalloc(&ctl, sizeof(Ctl)));
     int dev_cus = 0; CK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, 0));
