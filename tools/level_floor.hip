@@ -8,7 +8,7 @@
 //               the sweep's common task -- row/slot record, then state values)
 //   round2cold  round2, the records of every launch come from a fresh region (HBM misses, like the sweep's tables)
 //   round3..5   more dependent rounds (rows with 9-24 in-edges walk them in steps of eight)
-//   hipcc --offload-arch=gfx950 -O2 tools/level_floor.hip -o bin/level_floor && bin/level_floor [N] [G]
+//   hipcc --offload-arch=gfx950 -O2 -mllvm -amdgpu-kernarg-preload-count=16 tools/level_floor.hip -o bin/level_floor && bin/level_floor [N] [G]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -29,6 +29,18 @@ __global__ __launch_bounds__(256) void k_rounds(Desc d, const uint32_t *__restri
 #pragma unroll
     for (int r = 1; r < ROUNDS; ++r) x = cur[(x + (uint32_t)r * 64u) & mask];   // rounds 2..: values written by the previous launch (coalesced: a wave reads 64 consecutive words)
     nxt[t & mask] = (x + 4096u) & mask;                            // keeps lanes consecutive: x = wave base + lane throughout
+}
+
+// The same body with the pointers it needs first in the argument list and the file compiled with
+// -mllvm -amdgpu-kernarg-preload-count=16: the command processor hands the leading 16 dwords of scalar arguments to every
+// wave in SGPRs, so the first load does not wait for a load of the kernarg segment (struct arguments stop the preload).
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_rounds_pre(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ cur, uint32_t *__restrict__ nxt, uint32_t mask, Desc d) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t x = rec[t];
+#pragma unroll
+    for (int r = 1; r < ROUNDS; ++r) x = cur[(x + (uint32_t)r * 64u) & mask];
+    nxt[t & mask] = (x + 4096u + (uint32_t)d.w[3]) & mask;
 }
 
 // Persistent alternative: one resident grid loops over the levels; hand-off = agent-scope release of this workgroup's
@@ -122,6 +134,10 @@ int main(int argc, char **argv) {
     if (graph("empty1", [&](int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, s, d); })) return 1;
     if (graph("emptyG", [&](int) { hipLaunchKernelGGL(k_empty, dim3(G), dim3(256), 0, s, d); })) return 1;
     if (graph("round2", [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(G), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
+    if (graph("round2pre", [&](int i) { hipLaunchKernelGGL((k_rounds_pre<2>), dim3(G), dim3(256), 0, s, rec, st[i & 1], st[(i + 1) & 1], mask, d); })) return 1;
+    if (graph("round5pre", [&](int i) { hipLaunchKernelGGL((k_rounds_pre<5>), dim3(G), dim3(256), 0, s, rec, st[i & 1], st[(i + 1) & 1], mask, d); })) return 1;
+    if (graph("round2pre/64", [&](int i) { hipLaunchKernelGGL((k_rounds_pre<2>), dim3(64), dim3(256), 0, s, rec, st[i & 1], st[(i + 1) & 1], mask, d); })) return 1;
+    if (run("round2pre", [&](int i) { hipLaunchKernelGGL((k_rounds_pre<2>), dim3(G), dim3(256), 0, s, rec, st[i & 1], st[(i + 1) & 1], mask, d); })) return 1;
     if (graph("round5", [&](int i) { hipLaunchKernelGGL((k_rounds<5>), dim3(G), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
     for (int g2 : {16, 64, 256, 512, 2048, 4096}) {
         char nm[32]; snprintf(nm, sizeof nm, "round2/%dwg", g2);
