@@ -145,6 +145,68 @@ int main(int argc, char **argv) {
         if (graph(nm, [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(g2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
         if (run(nm, [&](int i) { hipLaunchKernelGGL((k_rounds<2>), dim3(g2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask); })) return 1;
     }
+    // Two bands on two streams: band B's launch of level l waits (event) for band A's launch of level l, which it reads;
+    // both bands run half the workgroups.  A skewed pipeline of the recombination-count ranges of the DP would look like this.
+    {
+        hipStream_t s2; CK(hipStreamCreate(&s2));
+        const int NB = 4000;
+        std::vector<hipEvent_t> evs(NB);
+        for (auto &evq : evs) CK(hipEventCreateWithFlags(&evq, hipEventDisableTiming));
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < NB; ++i) {
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask);
+                CK(hipEventRecord(evs[i], s));
+                CK(hipStreamWaitEvent(s2, evs[i], 0));
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s2, d, rec + (size_t)G * 128, st[i & 1] + 131072, st[(i + 1) & 1] + 131072, mask >> 1);
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("bands2      %7.3f us/level   (%d levels, 2 streams x %d workgroups, event per level)\n", 1e3 * ms / NB, NB, G / 2);
+        }
+        // the same pattern captured once into a hipGraph (fork/join through events) and replayed: no host work per level
+        {
+            const int M = 2000;
+            hipGraph_t g; hipGraphExec_t ge;
+            hipEvent_t fork, join; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            CK(hipEventRecord(fork, s)); CK(hipStreamWaitEvent(s2, fork, 0));
+            for (int i = 0; i < M; ++i) {
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask);
+                CK(hipEventRecord(evs[i], s));
+                CK(hipStreamWaitEvent(s2, evs[i], 0));
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s2, d, rec + (size_t)G * 128, st[i & 1] + 131072, st[(i + 1) & 1] + 131072, mask >> 1);
+            }
+            CK(hipEventRecord(join, s2)); CK(hipStreamWaitEvent(s, join, 0));
+            CK(hipStreamEndCapture(s, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("graph bands2 %6.3f us/level   (5 x %d levels, 2 branches x %d workgroups, edge per level)\n", 1e3 * ms / (5.0 * M), M, G / 2);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
+        // reference: two fully independent chains on the two streams
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < NB; ++i) {
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s, d, rec, st[i & 1], st[(i + 1) & 1], mask >> 1);
+                hipLaunchKernelGGL((k_rounds<2>), dim3(G / 2), dim3(256), 0, s2, d, rec + (size_t)G * 128, st[i & 1] + 131072, st[(i + 1) & 1] + 131072, mask >> 1);
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) printf("indep2      %7.3f us/level   (%d levels, 2 independent streams x %d workgroups)\n", 1e3 * ms / NB, NB, G / 2);
+        }
+        for (auto &evq : evs) CK(hipEventDestroy(evq));
+        CK(hipStreamDestroy(s2));
+    }
     if (argc > 3) return 0;                                         // any third argument: skip the persistent variants
     // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
     Ctl *ctl; CK(hipMalloc(&ctl, sizeof(Ctl)));
