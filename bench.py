@@ -151,7 +151,7 @@ def sketch_config4(cache, ctx, sk, dict_t, device, world, rank, backend, K, W, r
     n, rl = arr.shape
 
     def resident(lo, hi):
-        b = torch.from_numpy(np.ascontiguousarray(arr[lo:hi]).reshape(-1)).to(device)
+        b = torch.from_numpy(np.array(arr[lo:hi]).reshape(-1)).to(device)
         o = (torch.arange(hi - lo + 1, dtype=torch.int64) * rl).to(device)
         return b, o
     lo, hi = shard_bounds(n, world, rank)
