@@ -83,6 +83,7 @@ struct DpState {
     int64_t coop_cost_ns = 0;                           // model: barrier + LDS merge of a cooperative task
     int64_t use_coop = 1;                               // option: cooperative tasks for rows with many in-edges
     int64_t warm_rows = 1;                              // option: warm the row records before every chain walk
+    bool graph_failed = false;                          // capture or instantiation failed once: plain launches from then on
     int64_t graph_batch = -1;                           // option: levels per captured hipGraph (0 = plain launches, -1 = by level width)
     std::map<std::tuple<int, int, const void *>, hipGraphExec_t> graphs;   // (first level, end level, biased lattice pointer) -> replayable batch
     int64_t warm_ahead = 128;                           // option: sweep look-ahead, levels per batch (0 = off)
@@ -128,6 +129,7 @@ struct DpState {
     int seg_chunks = 1;                        // chunks per lattice segment (= all of them when the lattice is resident)
 };
 
+static void graphs_clear(DpState &S);
 static void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
     for (auto &kv : S.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     S.graphs.clear();
@@ -1907,15 +1909,20 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
             // Measured: MHC_4 (3.5 k cells per level) 390 -> 358 ms per sweep, also on the capturing pass; MHC-24 (265 k cells per
             // level, GPU-bound at 4.6 us) 651 -> 658 ms.  -1 picks 1,000-level batches for graphs below 32 k cells per level.
             const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : ((int64_t)(S.cells / (uint64_t)std::max(S.L, 1)) < 32768 ? 1000 : 0);
-            const bool use_graph = gb > 0 && n_win == 1 && S.sync_every == 0;
+            // A stream that cannot be captured (e.g. a caller-provided legacy stream) or a failed instantiation switches the
+            // context back to plain launches for good; the batch at hand is then issued again, plainly.
             for (int l0 = seg.begin; l0 < seg.end;) {
+                const bool use_graph = gb > 0 && n_win == 1 && S.sync_every == 0 && !S.graph_failed;
                 const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, seg.end) : seg.end;
                 hipGraphExec_t *slot = nullptr;
+                bool capturing = false;
                 if (use_graph) {
                     slot = &S.graphs[std::make_tuple(l0, l1, (const void *)bp_biased)];
                     if (*slot) { DG_HIP(hipGraphLaunch(*slot, s)); n_launch += l1 - l0; l0 = l1; continue; }
-                    DG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+                    else { (void)hipGetLastError(); S.graph_failed = true; continue; }
                 }
+                const int64_t n_launch_before = n_launch;
                 for (int l = l0; l < l1; ++l) {
                     LevelDesc &d = S.descs[l];
                     if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
@@ -1993,11 +2000,15 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
                     // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
                     if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
                 }
-                if (use_graph) {
+                if (capturing) {
                     hipGraph_t cg = nullptr;
-                    DG_HIP(hipStreamEndCapture(s, &cg));
-                    DG_HIP(hipGraphInstantiate(slot, cg, nullptr, nullptr, 0));
-                    DG_HIP(hipGraphDestroy(cg));
+                    const bool ok = hipStreamEndCapture(s, &cg) == hipSuccess && cg && hipGraphInstantiate(slot, cg, nullptr, nullptr, 0) == hipSuccess;
+                    if (cg) (void)hipGraphDestroy(cg);
+                    if (!ok) {                                          // nothing of this batch has run: issue it again without a graph
+                        (void)hipGetLastError();
+                        *slot = nullptr; S.graph_failed = true; n_launch = n_launch_before;
+                        continue;
+                    }
                     DG_HIP(hipGraphLaunch(*slot, s));
                 }
                 l0 = l1;

@@ -227,6 +227,21 @@ def test_dp_graph_batches(gpu_ctx, batch, seg, chunk):
             gpu_ctx.dp_set_option("lattice_chunk_cells", 1 << 31)
 
 
+def test_dp_graph_batches_fall_back_on_uncapturable_stream(gpu_ctx):
+    """a context that adopted the legacy null stream cannot capture: the narrow-graph batches must fall back to plain
+    launches (same answer), not fail"""
+    ctx = capi.Context(0)
+    try:
+        ctx.set_stream(0)                                       # hipStreamLegacy: stream capture is not allowed on it
+        ctx.dp_set_option("graph_batch", 7)
+        for seed in (61, 62):
+            g = graphgen.random_levelized(8500 + seed, max_width=12, n_levels=120, R=5, p_colour=0.5)
+            _dp_both(ctx, g)
+            assert ctx.dp_run().key() == ctx.dp_run().key()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("chunk_cells", [1, 3000, 150000])
 def test_dp_chunked_lattice(gpu_ctx, chunk_cells):
     """the resident back-pointer lattice is a pool of chunks mapped by a background thread while the sweep runs;
