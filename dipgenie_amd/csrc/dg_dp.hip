@@ -522,6 +522,20 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
     const int evr = (int)((sl.y >> 20) & 0xFFu);                       // rank of this lane's in-edge inside its column's list
     const int du = (int)rr.y;
+#ifdef DG_SKELETON                                                      // timing probe: geometry + the two record loads + the stores, no task body
+    {
+        const int pj2s = lane_up1(j2);
+        if (act & ((lane == 0) | (pj2s != j2)) & (du >= 0)) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) if (r0 + q < RP) {
+                const int idx = (i2 * RP + r0 + q) * d.k2 + j2;
+                nxt[idx] = NEG_INF;
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], 0xFFFFu); else A.bp[d.bp_off + idx] = (uint16_t)0xFFFFu; }
+            }
+        }
+        return;
+    }
+#endif
     if (COOP == 1 && du > COOP_MIN) return;
     uint32_t mypu = 0;
     if (du > 2 && lane < du) mypu = A.in_edge[rr.x + lane];            // du <= 64 on this path
