@@ -164,6 +164,18 @@ def e2e():
     return cases
 
 
+def dpg():
+    """toy levelized DP graphs (dg_dp_graph dumps, what dg_dp_load_graph receives) of the two toy runs: written by the host
+    pipeline behind the oracle backend (tests/harness/dg_host_oracle -X -D); the DP values they must give (8 and 14) are
+    the reference's (e2e.json: toy2_p2, toy1_p2)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "harness")])
+    har = os.path.join(ROOT, "tests", "harness", "dg_host_oracle")
+    D = os.path.join(ROOT, "tests", "data")
+    for out, g, r, extra in (("toy2_R2", "test2.gfa", "read2.fa", []), ("toy1_k5w3_R2", "test.gfa", "read.fa", ["-k5", "-w3"])):
+        subprocess.check_call([har, "-q", "-t2", "-p2", "-R2", *extra, "-X", "-D", os.path.join(HERE, out), "-g", os.path.join(D, g),
+                               "-r", os.path.join(D, r), "-o", os.path.join("/tmp", out + ".fa")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     what = sys.argv[1:] or ["sketch", "fit", "e2e"]
@@ -171,5 +183,7 @@ if __name__ == "__main__":
         json.dump(kat_sketch(), open(os.path.join(HERE, "kat_sketch.json"), "w"), indent=0)
     if "e2e" in what:
         json.dump(e2e(), open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+    if "dpg" in what:
+        dpg()
     if "fit" in what:
         json.dump(kat_fit(), open(os.path.join(HERE, "kat_fit.json"), "w"), indent=1)
