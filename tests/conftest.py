@@ -18,6 +18,13 @@ def _make(path, *targets):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, path), *targets])
 
 
+def pytest_sessionstart(session):
+    """a fresh checkout has no built artefacts, and test modules import dipgenie_amd.capi (which refuses to load without
+    libdipgenie_hip.so) at collection time: cross-compile the HIP library first (hipcc needs no GPU)"""
+    if not os.path.exists(os.path.join(ROOT, "dipgenie_amd", "csrc", "libdipgenie_hip.so")):
+        _make("dipgenie_amd/csrc")
+
+
 @pytest.fixture(scope="session")
 def built_cpu():
     """oracle restatement, host pipeline objects and the host+oracle harness (CPU only)."""
