@@ -22,8 +22,16 @@ struct LazyCtx {
     dg_ctx *ctx = nullptr;
     std::string err;
     bool joined = false;
-    void start(int device) {
-        th = std::thread([this, device] { ctx = dg_create(device); if (!ctx) err = dg_last_error(); });
+    void start(int device, int k, int w) {
+        th = std::thread([this, device, k, w] {
+            ctx = dg_create(device);
+            if (!ctx) { err = dg_last_error(); return; }
+            // first launch from the sketch module loads its code object and makes the first device allocations (~10 ms):
+            // paid here, beside the GFA parse, instead of in front of the first haplotype
+            const std::string warm(256, 'A');
+            uint64_t *h = nullptr; int64_t *p = nullptr; int64_t n = 0;
+            if (k >= 1 && k <= 255 && w >= 1 && dg_sketch_haplotype(ctx, warm.data(), (int64_t)warm.size(), k, w, &h, &p, &n) == DG_OK) { dg_free(h); dg_free(p); }
+        });
     }
     dg_ctx *get() {
         if (!joined) { th.join(); joined = true; }
@@ -103,7 +111,7 @@ int main(int argc, char **argv) {
         return 1;
     }
     const double t0 = dg::now_s();
-    g_lazy.start(device);
+    g_lazy.start(device, p.opt.k, p.opt.w);
     p.be.ctx = &g_lazy;
     p.be.sketch_reads = b_sketch_reads;
     p.be.sketch_haplotype = b_sketch_hap;
