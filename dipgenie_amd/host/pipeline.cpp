@@ -372,6 +372,38 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             const int64_t b = bucket_off[r], e = bucket_off[r + 1];
             if (b == e) continue;
             const int32_t n = (int32_t)(e - b);
+            // The filter (:615-622) only asks whether some vertex path occurs >= thr times; equal keys <=> equal vertex
+            // lists, so the lists themselves are grouped first (any order consistent with equality serves for counting).
+            // Most ids are dropped here -- every haplotype carries the k-mer on the same path -- without a key being built.
+            if ((float)n >= thr) {
+                auto lst = [&](int32_t t) {
+                    const Raw &o = raw[b + t];
+                    const auto &ix = kmer_index[o.h];
+                    return std::pair<const int32_t *, uint32_t>(ix.v.data() + ix.voff[o.m], ix.voff[o.m + 1] - ix.voff[o.m]);
+                };
+                bool dropped = false;
+                const auto first = lst(0);
+                int32_t same = 1;
+                while (same < n) { const auto q = lst(same); if (q.second != first.second || !std::equal(q.first, q.first + q.second, first.first)) break; ++same; }
+                if (same == n) dropped = true;                          // the common case: one path, n >= thr occurrences
+                else {
+                    order.resize(n);
+                    std::iota(order.begin(), order.end(), 0);
+                    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                        const auto a = lst(x), c2 = lst(y);
+                        if (a.second != c2.second) return a.second < c2.second;
+                        return std::lexicographical_compare(a.first, a.first + a.second, c2.first, c2.first + c2.second);
+                    });
+                    for (int32_t i = 0; i < n && !dropped;) {
+                        const auto a = lst(order[i]);
+                        int32_t j = i + 1;
+                        while (j < n) { const auto q = lst(order[j]); if (q.second != a.second || !std::equal(q.first, q.first + q.second, a.first)) break; ++j; }
+                        if ((float)(j - i) >= thr) dropped = true;
+                        i = j;
+                    }
+                }
+                if (dropped) continue;                                  // :624-632 id dropped entirely
+            }
             arena.clear();
             koff.assign(1, 0);
             for (int32_t t = 0; t < n; ++t) {
@@ -391,14 +423,6 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             std::iota(order.begin(), order.end(), 0);
             // std::map<std::string,...> iteration = lexicographic on the key; inside a key, push order
             std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key(x) < key(y); });
-            bool all_haps = false;                                     // :615-622
-            for (int32_t i = 0; i < n;) {
-                int32_t j = i + 1;
-                while (j < n && key(order[j]) == key(order[i])) ++j;
-                if ((float)(j - i) >= thr) { all_haps = true; break; }
-                i = j;
-            }
-            if (all_haps) continue;                                    // :624-632 id dropped entirely
             // Anchor_hits_1[r][h] in map-iteration order, then std::sort per (r,h) (:641-663)
             byhap = order;                                             // haplotype ascending, map-iteration order inside one
             std::stable_sort(byhap.begin(), byhap.end(), [&](int32_t x, int32_t y) { return raw[b + x].h < raw[b + y].h; });
