@@ -989,8 +989,24 @@ int Pipeline::solve(std::string &err) {
     g.adj_dst.resize(elog.size());
     g.adj_w.resize(elog.size());
     {
+        // stable scatter by source, in parallel: every thread owns a contiguous range of sources (balanced by edge
+        // count) and reads the whole push log in order, so a vertex keeps its push order as in the serial loop
         std::vector<int64_t> fill(g.adj_off.begin(), g.adj_off.end() - 1);
-        for (const ELog &e : elog) { const int64_t o = fill[e.src]++; g.adj_dst[o] = e.dst; g.adj_w[o] = e.w; }
+        const int T = std::max(1, std::min(opt.threads, 32));
+        std::vector<int32_t> cut(T + 1, nvert);
+        cut[0] = 0;
+        for (int t = 1; t < T; ++t) {
+            const int64_t want = (int64_t)elog.size() * t / T;
+            cut[t] = (int32_t)(std::lower_bound(g.adj_off.begin(), g.adj_off.end(), want) - g.adj_off.begin());
+            cut[t] = std::min(std::max(cut[t], cut[t - 1]), nvert);
+        }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+        for (int t = 0; t < T; ++t) {
+            const int32_t lo = cut[t], hi = cut[t + 1];
+            if (lo >= hi) continue;
+            for (const ELog &e : elog)
+                if (e.src >= lo && e.src < hi) { const int64_t o = fill[e.src]++; g.adj_dst[o] = e.dst; g.adj_w[o] = e.w; }
+        }
     }
     { std::vector<ELog>().swap(elog); }
     g.col_off.assign((size_t)nvert + 1, 0);
