@@ -14,9 +14,12 @@
 //     s_het from the colour lists of the L winning edge pairs;
 //   * score deltas (:604-624) do not depend on r nor on other levels: a launch fills, for every transition that
 //     touches a colour, the T x T matrix delta[e_u][e_v] (uint16), T = #in-edges of the destination level;
-//     colourless transitions (73 % on MHC_4) skip the lookup;
+//     colourless transitions (73 % on MHC_4) skip the lookup; per in-edge colour flags and "self" scores answer every
+//     pair with at most one coloured edge without a merge, the rest are queued in LDS and merged densely;
 //   * one launch per level (the levels are a dependency chain); the host picks the chunk size RC per level from a
-//     cost model and gives rows with many in-edges cooperative workgroups.
+//     cost model and gives rows with many in-edges cooperative workgroups; every 128 levels a look-ahead launch
+//     streams the next batch's graph tables through the Infinity Cache; on narrow graphs the launches of 1,000
+//     levels are captured into a hipGraph and replayed (the chain is host-bound there).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -129,7 +132,6 @@ struct DpState {
     int seg_chunks = 1;                        // chunks per lattice segment (= all of them when the lattice is resident)
 };
 
-static void graphs_clear(DpState &S);
 static void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
     for (auto &kv : S.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     S.graphs.clear();
