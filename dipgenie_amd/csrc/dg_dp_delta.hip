@@ -1,0 +1,131 @@
+// Score-delta precompute (approximator.cpp:604-624): delta[e_u][e_v] = inter + symd for every coloured transition.
+// The deltas depend neither on r nor on other levels, so they are filled for a whole window of levels in one launch,
+// off the sweep's dependency chain.
+#include <algorithm>
+
+#include "dg_dp_setops.hpp"
+
+namespace dgi {
+
+// Per in-edge (source -> destination), once per graph: which of the four colour lists that an edge pair can contribute are
+// non-empty -- bit 0 Hom(source), bit 1 Hom(destination), bit 2 Het(source), bit 3 Het(destination).  Most edges of a
+// coloured transition carry no colour at all; with the flags the delta kernel answers those pairs from two byte loads
+// instead of sixteen offset loads, and pairs with ONE coloured edge from that edge's own score (self[]).
+__global__ __launch_bounds__(64) void dp_edge_flags_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ in_edge,
+                                                           const int32_t *__restrict__ in_dst, ColourCsr col, uint8_t *__restrict__ flags,
+                                                           uint16_t *__restrict__ self) {
+    const int l = (int)blockIdx.x + 1;
+    if (l >= L) return;
+    const LevelDesc d = descs[l];
+    for (int e = (int)threadIdx.x; e < d.T; e += 64) {
+        const int u1 = d.a0 + (int)(in_edge[d.in_base + e] & 0x7FFFFFFFu), u2 = in_dst[d.in_base + e];
+        const uint32_t f = (col.hom_off[u1 + 1] > col.hom_off[u1] ? 1u : 0u) | (col.hom_off[u2 + 1] > col.hom_off[u2] ? 2u : 0u) |
+                           (col.het_off[u1 + 1] > col.het_off[u1] ? 4u : 0u) | (col.het_off[u2 + 1] > col.het_off[u2] ? 8u : 0u);
+        flags[d.in_base + e] = (uint8_t)f;
+        // score of this edge paired with an edge that carries no colour: |Hom(u1) n Hom(u2)| + |Het(u1) /\ Het(u2)|
+        int sc = 0;
+        if ((f & 3u) == 3u) {
+            const int64_t a = col.hom_off[u1], b = col.hom_off[u2];
+            sc += union2x2<false>(col.hom_col + a, (int)(col.hom_off[u1 + 1] - a), nullptr, 0, col.hom_col + b, (int)(col.hom_off[u2 + 1] - b), nullptr, 0);
+        }
+        if (f & 12u) {
+            const int64_t a = col.het_off[u1], b = col.het_off[u2];
+            sc += union2x2<true>(col.het_col + a, (int)(col.het_off[u1 + 1] - a), nullptr, 0, col.het_col + b, (int)(col.het_off[u2 + 1] - b), nullptr, 0);
+        }
+        self[d.in_base + e] = (uint16_t)sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restrict__ descs,
+                                                       const int32_t *__restrict__ dtrans,      // coloured transition -> level
+                                                       const int64_t *__restrict__ dblk_first,  // first block of each coloured transition
+                                                       int n_dtrans, const uint32_t *__restrict__ in_edge,
+                                                       const int32_t *__restrict__ in_dst, ColourCsr col,
+                                                       uint16_t *__restrict__ delta /* biased like SweepArgs::delta */, int64_t block0,
+                                                       const uint8_t *__restrict__ eflags, const uint16_t *__restrict__ eself) {
+    __shared__ int s_t;
+    if (threadIdx.x == 0) {   // binary search: last transition whose first block <= blockIdx.x
+        int lo = 0, hi = n_dtrans - 1;
+        const int64_t b = block0 + blockIdx.x;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (dblk_first[mid] <= b) lo = mid; else hi = mid - 1; }
+        s_t = lo;
+    }
+    __syncthreads();
+    const int t = s_t;
+    const LevelDesc d = descs[dtrans[t]];
+    const int64_t n = (int64_t)d.T * d.T;
+    const int64_t first = (block0 + (int64_t)blockIdx.x - dblk_first[t]) * DELTA_PER_BLOCK;
+    uint16_t *out = delta + d.delta_off;
+    // Pass 1, eight entries per thread at a time (independent index arithmetic and flag loads go out back to back): pairs whose
+    // four colour lists cannot contribute -- the vast majority -- are answered with 0 on the spot, the others are queued in
+    // LDS.  Pass 2 works the queue off densely: the sorted-list merges are the expensive part (16 dependent loads and
+    // data-dependent loops), and with one coloured in-edge in ten nearly every wave used to hold a few of them, so every
+    // wave paid for them (34 ms on MHC-24; 2.6 ms with the merges switched off).
+    __shared__ uint16_t s_q[DELTA_PER_BLOCK];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const bool small = n < ((int64_t)1 << 31);
+    for (int q0 = 0; q0 < DELTA_PER_BLOCK / 256; q0 += 8) {
+        int64_t ee[8];
+        uint32_t f[8];                                                    // bit 8: entry exists; bits 0-7 / 16-23: flags of e_u / e_v
+        int eu8[8], ev8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t e = first + (int64_t)(q0 + u) * 256 + threadIdx.x;
+            const bool ok = e < n;
+            const int64_t ec = ok ? e : 0;
+            const int eu = small ? (int)((uint32_t)ec / (uint32_t)d.T) : (int)(ec / d.T);
+            const int ev = (int)(ec - (int64_t)eu * d.T);
+            ee[u] = e; eu8[u] = eu; ev8[u] = ev;
+            f[u] = ok ? ((uint32_t)eflags[d.in_base + eu] | ((uint32_t)eflags[d.in_base + ev] << 16) | 0x100u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (!(f[u] & 0x100u)) continue;
+            const uint32_t fu = f[u] & 0xFFu, fv = f[u] >> 16;
+            if ((fu | fv) == 0u) out[ee[u]] = 0;                            // no colour on either edge
+            else if (fv == 0u) out[ee[u]] = eself[d.in_base + eu8[u]];      // one coloured edge: its own score
+            else if (fu == 0u) out[ee[u]] = eself[d.in_base + ev8[u]];
+            else s_q[atomicAdd(&s_n, 1)] = (uint16_t)((q0 + u) * 256 + (int)threadIdx.x);   // both coloured: merge (pass 2)
+        }
+    }
+    __syncthreads();
+    const int nq = s_n;
+    for (int i = (int)threadIdx.x; i < nq; i += 256) {
+        const int64_t e = first + (int64_t)s_q[i];
+        const int eu = small ? (int)((uint32_t)e / (uint32_t)d.T) : (int)(e / d.T);
+        const int ev = (int)(e - (int64_t)eu * d.T);
+        const uint32_t ff = (uint32_t)eflags[d.in_base + eu] | (uint32_t)eflags[d.in_base + ev];
+        const uint32_t pu = in_edge[d.in_base + eu], pv = in_edge[d.in_base + ev];
+        const int u1 = d.a0 + (int)(pu & 0x7FFFFFFFu), v1 = d.a0 + (int)(pv & 0x7FFFFFFFu);
+        const int u2 = in_dst[d.in_base + eu], v2 = in_dst[d.in_base + ev];
+        int sc = 0;
+        if ((ff & 3u) == 3u) sc += score_inter(col, u1, v1, u2, v2);
+        if ((ff & 12u) != 0u) sc += score_symd(col, u1, v1, u2, v2);
+        out[e] = (uint16_t)sc;
+    }
+}
+
+void delta_launch_edge_flags(const DpState &S, hipStream_t s) {
+    hipLaunchKernelGGL(dp_edge_flags_kernel, dim3((unsigned)std::max(S.L - 1, 1)), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_in_edge.as<uint32_t>(),
+                       S.d_in_dst.as<int32_t>(), colour_csr(S), S.d_eflag.as<uint8_t>(), S.d_eself.as<uint16_t>());
+}
+
+const uint16_t *delta_launch_window(DpState &S, int w, hipStream_t s) {
+    const int t0 = S.dwin_t[w], t1 = S.dwin_t[w + 1];
+    const uint16_t *biased = S.d_delta.as<uint16_t>();
+    if (t1 > t0) {
+        const int64_t b0 = S.dblk_first_host[t0], b1 = S.dblk_first_host[t1];
+        const int64_t base_off = S.descs[S.dtrans_host[t0]].delta_off;          // global entry offset of the window's first matrix
+        uint16_t *out = S.d_delta.as<uint16_t>() + DELTA_PAD - base_off;
+        hipLaunchKernelGGL(dp_delta_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0, s, S.d_descs.as<LevelDesc>(), S.d_dtrans.as<int32_t>(),
+                           S.d_dblk_first.as<int64_t>(), (int)S.dtrans_host.size(), S.d_in_edge.as<uint32_t>(), S.d_in_dst.as<int32_t>(), colour_csr(S),
+                           out, b0, S.d_eflag.as<uint8_t>(), S.d_eself.as<uint16_t>());
+        biased = out;
+    }
+    S.cur_win = w;
+    return biased;
+}
+
+}  // namespace dgi

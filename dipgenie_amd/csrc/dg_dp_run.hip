@@ -1,0 +1,349 @@
+// dg_dp_run and the DP entry points of the C ABI: issues the level chain (plain launches or replayed hipGraph batches),
+// drives lattice chunks / segments (checkpoint + recompute when the back-pointer lattice outgrows HBM), the score-delta
+// windows and the traceback, and turns the edge records into the two weighted-edge lists (approximator.cpp:757-785).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include "dg_dp.hpp"
+
+namespace dgi {
+
+double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
+    for (auto &kv : S.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    S.graphs.clear();
+}
+
+void dp_state_free(DpState *s) {
+    if (!s) return;
+    graphs_clear(*s);
+    { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
+    if (s->pool.th.joinable()) s->pool.th.join();
+    for (void *q : s->pool.chunks) (void)hipFree(q);
+    for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lattice chunk pool
+// ---------------------------------------------------------------------------------------------
+// Ask for `target` chunks (the latest request wins): starts the allocation thread if chunks are missing.  Chunks
+// already mapped beyond the target are kept (hipFree of 8 GB costs ~0.1 s) unless pool_trim is called.  Returns at once.
+void pool_request(DpState &S, int device, size_t target) {
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    S.pool.target = std::max(target, S.pool.chunks.size());
+    if (S.pool.running || S.pool.chunks.size() >= S.pool.target) return;
+    if (S.pool.th.joinable()) { lk.unlock(); S.pool.th.join(); lk.lock(); }
+    S.pool.running = true;
+    S.pool.failed = false;
+    DpState *Sp = &S;
+    S.pool.th = std::thread([Sp, device]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            size_t bytes;
+            {
+                std::unique_lock<std::mutex> lk2(Sp->pool.mu);
+                Sp->pool.cv.wait(lk2, [&] { return !Sp->pool.paused; });
+                if (Sp->pool.chunks.size() >= Sp->pool.target) { Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
+                bytes = Sp->pool.chunk_units * 2;
+            }
+            void *q = nullptr;
+            const hipError_t e = hipMalloc(&q, bytes);
+            std::unique_lock<std::mutex> lk2(Sp->pool.mu);
+            if (e != hipSuccess) { (void)hipGetLastError(); Sp->pool.failed = true; Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
+            Sp->pool.chunks.push_back(q);
+            Sp->pool.cv.notify_all();
+            lk2.unlock();
+            // HIP calls of other threads queue on a runtime lock this thread would otherwise win again at once
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    });
+}
+PoolPause::PoolPause(DpState &s) : S(s) { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.paused = true; }
+PoolPause::~PoolPause() { { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.paused = false; } S.pool.cv.notify_all(); }
+// free chunks beyond `keep` (and stop asking for more than that)
+void pool_trim(DpState &S, size_t keep) {
+    { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.target = std::min(S.pool.target, keep); }
+    if (S.pool.th.joinable()) S.pool.th.join();               // it stops at the next chunk boundary
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    while (S.pool.chunks.size() > keep) { (void)hipFree(S.pool.chunks.back()); S.pool.chunks.pop_back(); }
+    S.pool.running = false;
+}
+// wait until chunk c exists; nullptr if the allocation failed
+void *pool_wait(DpState &S, size_t c) {
+    std::unique_lock<std::mutex> lk(S.pool.mu);
+    S.pool.cv.wait(lk, [&] { return S.pool.chunks.size() > c || S.pool.failed || !S.pool.running; });
+    return S.pool.chunks.size() > c ? S.pool.chunks[c] : nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one DP pass over the resident graph
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Run {
+    dg_ctx *c;
+    DpState &S;
+    hipStream_t s;
+    SweepLaunch X;
+    int64_t n_launch = 0;
+    double host_enqueue_s = 0;                          // host time spent issuing the sweep's launches (DG_DEBUG)
+    std::vector<uint16_t *> pool_base;
+
+    Run(dg_ctx *c_, DpState &S_) : c(c_), S(S_), s(c_->stream) { sweep_prepare(S, X); }
+    int n_win() const { return (int)S.dwin_t.size() - 1; }
+    int32_t *state_ptr(int level) const { return S.d_val[level & 1].as<int32_t>() + S.pad_front; }
+    size_t level_cells(int level) const {               // state size of a level (level 0: the source, k = 1)
+        const int64_t k = level == 0 ? 1 : S.descs[level].k2;
+        return (size_t)(k * k * S.RP);
+    }
+    void load_window(int w) { X.A.delta = X.F.delta = delta_launch_window(S, w, s); }
+
+    // issues the launches of destination levels [l0, l1) of the range that began at lb
+    int issue_levels(int l0, int l1, int lb, int le) {
+        for (int l = l0; l < l1; ++l) {
+            if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
+            if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0) {
+                // tables of the batch after this one (and, at the start of a range, of this one too)
+                const int q0 = l == lb ? l : (int)std::min<int64_t>(l + S.warm_ahead, le), q1 = (int)std::min<int64_t>(l + 2 * S.warm_ahead, le);
+                if (q1 > q0) sweep_warm_tables(S, X, q0, q1, s);
+            }
+            sweep_launch_level(S, X, l, s);
+            ++n_launch;
+            // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
+            if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
+        }
+        return DG_OK;
+    }
+
+    // Sweeps destination levels [lb, le).  bp_biased = lattice pointer minus the offset of level lb's first cell
+    // (so the kernels keep using the global LevelDesc::bp_off), or nullptr for a value-only pass.
+    // Issuing a level costs the host 3-4.5 us (hipLaunchKernelGGL), the GPU 2-3 us on narrow levels: batches of levels are
+    // captured once into hipGraphs and replayed on later passes over the same resident graph (option graph_batch).
+    // Measured: MHC_4 (3.5 k cells per level) 390 -> 358 ms per sweep, also on the capturing pass; MHC-24 (265 k cells per
+    // level, GPU-bound) 651 -> 658 ms.  -1 picks 1,000-level batches for graphs below 32 k cells per level.
+    // A stream that cannot be captured (e.g. a caller-provided legacy stream) or a failed instantiation switches the
+    // context back to plain launches for good; the batch at hand is then issued again, plainly.
+    int sweep_range(int lb, int le, uint16_t *bp_biased) {
+        X.A.bp = bp_biased; X.F.bp = bp_biased;
+        const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : ((int64_t)(S.cells / (uint64_t)std::max(S.L, 1)) < 32768 ? 1000 : 0);
+        for (int l0 = lb; l0 < le;) {
+            const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
+            const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, le) : le;
+            hipGraphExec_t *slot = nullptr;
+            bool capturing = false;
+            if (use_graph) {
+                slot = &S.graphs[std::make_tuple(l0, l1, (const void *)bp_biased)];
+                if (*slot) { DG_HIP(hipGraphLaunch(*slot, s)); n_launch += l1 - l0; l0 = l1; continue; }
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+                else { (void)hipGetLastError(); S.graph_failed = true; continue; }
+            }
+            const int64_t n_launch_before = n_launch;
+            if (int rc = issue_levels(l0, l1, lb, le)) return rc;
+            if (capturing) {
+                hipGraph_t cg = nullptr;
+                const bool ok = hipStreamEndCapture(s, &cg) == hipSuccess && cg && hipGraphInstantiate(slot, cg, nullptr, nullptr, 0) == hipSuccess;
+                if (cg) (void)hipGraphDestroy(cg);
+                if (!ok) {                                          // nothing of this batch has run: issue it again without a graph
+                    (void)hipGetLastError();
+                    *slot = nullptr; S.graph_failed = true; n_launch = n_launch_before;
+                    continue;
+                }
+                DG_HIP(hipGraphLaunch(*slot, s));
+            }
+            l0 = l1;
+        }
+        return DG_OK;
+    }
+
+    // Launches issued while the pool thread is still mapping chunks would each queue behind a multi-GB hipMalloc,
+    // so there is nothing to overlap: wait for every chunk this run uses first.
+    int wait_for_chunks() {
+        if (S.d_bp.p) return DG_OK;
+        const double tw0 = wall_s();
+        const size_t need = (size_t)std::min(S.seg_chunks, (int)S.chunk_begin.size() - 1);
+        if (!pool_wait(S, need - 1)) { set_error("back-pointer lattice: hipMalloc of a %.1f GB chunk failed", S.pool.chunk_units * 2 / 1e9); return DG_ERR_OOM; }
+        std::unique_lock<std::mutex> lk(S.pool.mu);
+        for (size_t q = 0; q < need; ++q) pool_base.push_back((uint16_t *)S.pool.chunks[q]);
+        if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: waited %.3f s for lattice chunks\n", wall_s() - tw0);
+        return DG_OK;
+    }
+
+    // Sweeps the chunks [c0, c1) with back-pointers into pool chunks 0 .. c1-c0-1 (or the one exact buffer), then walks
+    // them last first; from_sink = this is the walk that starts at the sink.
+    int sweep_and_walk(int c0, int c1, bool from_sink, bool mark_forward_end) {
+        std::vector<uint16_t *> biased(c1 - c0);
+        for (int ch = c0; ch < c1; ++ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            uint16_t *base = S.d_bp.p ? S.d_bp.as<uint16_t>() : pool_base[ch - c0];
+            biased[ch - c0] = base - S.descs[lb].bp_off;
+            const double th0 = wall_s();
+            if (int rc = sweep_range(lb, le, biased[ch - c0])) return rc;
+            host_enqueue_s += wall_s() - th0;
+        }
+        if (mark_forward_end) DG_HIP(hipEventRecord(S.ev[2], s));
+        for (int ch = c1 - 1; ch >= c0; --ch) {
+            const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
+            trace_launch_warm_rows(S, lb, le, s);
+            trace_launch_chain(S, le - 1, lb, biased[ch - c0], from_sink && ch == c1 - 1 ? state_ptr(S.L - 1) : (const int32_t *)nullptr, s);
+        }
+        return DG_OK;
+    }
+
+    int forward_and_trace() {
+        const int n_seg = (int)S.seg_begin.size() - 1, n_chunks_all = (int)S.chunk_begin.size() - 1;
+        DG_HIP(hipEventRecord(S.ev[0], s));
+        S.cur_win = -1;
+        if (n_win() == 1 && S.n_delta_blocks > 0) load_window(0);      // everything fits: computed once, up front (delta_ms)
+        DG_HIP(hipEventRecord(S.ev[1], s));
+        if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
+        sweep_init_state(S, s);
+        if (n_seg == 1) {
+            // whole lattice resident: one sweep with back-pointers, then the chain walk chunk by chunk, last first
+            if (int rc = sweep_and_walk(0, S.d_bp.p ? 1 : n_chunks_all, true, true)) return rc;
+        } else {
+            // pass 1: values only, keeping the state in front of every segment
+            const int64_t dig = S.want_digest;
+            for (int sg = 0; sg < n_seg; ++sg) {
+                if (sg > 0)
+                    DG_HIP(hipMemcpyAsync(S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], state_ptr(S.seg_begin[sg] - 1),
+                                          4 * level_cells(S.seg_begin[sg] - 1), hipMemcpyDeviceToDevice, s));
+                if (int rc = sweep_range(S.seg_begin[sg], S.seg_begin[sg + 1], nullptr)) return rc;
+            }
+            DG_HIP(hipEventRecord(S.ev[2], s));                 // (the re-sweeps below are booked under traceback_ms)
+            // pass 2: last segment first -- restore its input state, re-sweep its chunks with back-pointers, walk them
+            S.want_digest = 0;                                  // digests were accumulated in pass 1
+            for (int sg = n_seg - 1; sg >= 0; --sg) {
+                const int lb = S.seg_begin[sg];
+                if (sg > 0)
+                    DG_HIP(hipMemcpyAsync(state_ptr(lb - 1), S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], 4 * level_cells(lb - 1), hipMemcpyDeviceToDevice, s));
+                else
+                    sweep_init_state(S, s);
+                const int c0 = sg * S.seg_chunks, c1 = std::min(n_chunks_all, c0 + S.seg_chunks);
+                if (int rc = sweep_and_walk(c0, c1, sg == n_seg - 1, false)) { S.want_digest = dig; return rc; }
+            }
+            S.want_digest = dig;
+        }
+        trace_launch_finish(S, s);
+        DG_HIP(hipEventRecord(S.ev[3], s));
+        DG_HIP(hipGetLastError());
+        return DG_OK;
+    }
+};
+
+}  // namespace
+
+static int dp_run(dg_ctx *c, dg_dp_result *res) {
+    DpState *Sp = c->dp;
+    if (!Sp || !Sp->loaded) { set_error("dg_dp_run: no graph loaded"); return DG_ERR_STATE; }
+    if (!res) { set_error("dg_dp_run: null result"); return DG_ERR_ARG; }
+    DpState &S = *Sp;
+    Run run(c, S);
+    hipStream_t s = c->stream;
+    if (int rc = run.wait_for_chunks()) return rc;
+    if (int rc = run.forward_and_trace()) return rc;
+    TraceOut to;
+    std::vector<int32_t> edges(4 * (size_t)S.cap);
+    DG_HIP(hipMemcpyAsync(&to, S.d_trace.p, sizeof to, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(edges.data(), S.d_edges.p, 4 * edges.size(), hipMemcpyDeviceToHost, s));
+    if (S.want_digest) {
+        S.digest_host.assign(S.L, 0);
+        DG_HIP(hipMemcpyAsync(S.digest_host.data(), S.d_digest.p, 8 * (size_t)S.L, hipMemcpyDeviceToHost, s));
+    }
+    DG_HIP(hipStreamSynchronize(s));
+    if (getenv("DG_DEBUG"))
+        fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)run.n_launch, 1e3 * run.host_enqueue_s,
+                1e6 * run.host_enqueue_s / (double)std::max<int64_t>(run.n_launch, 1));
+    DG_HIP(hipEventElapsedTime(&S.timing.delta_ms, S.ev[0], S.ev[1]));
+    DG_HIP(hipEventElapsedTime(&S.timing.forward_ms, S.ev[1], S.ev[2]));
+    DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
+    DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
+    S.timing.n_forward_launches = run.n_launch;
+    if (to.value == CHAIN_CORRUPT) { set_error("back-pointer lattice is corrupt: the chain walk left its level (a level was not swept?)"); return DG_ERR_STATE; }
+    if (to.overflow || to.n_e > S.cap) { set_error("traceback edge list overflow (%d > %d)", to.n_e, S.cap); return DG_ERR_STATE; }
+    res->value = to.value; res->s_het = to.s_het;
+    res->cells = S.cells; res->relaxations = S.relaxations;
+    // records arrive in arbitrary order: path order = ascending level (the two records of the last level are equal)
+    std::vector<int> order(to.n_e);
+    for (int q = 0; q < to.n_e; ++q) order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return edges[a] < edges[b]; });
+    int n1 = 0, n2 = 0;
+    for (int q : order) {
+        const int from = edges[S.cap + q], tov = edges[2 * S.cap + q];
+        if (edges[3 * S.cap + q] == 0) { if (n1 < res->cap && res->p1_from && res->p1_to) { res->p1_from[n1] = from; res->p1_to[n1] = tov; } ++n1; }
+        else { if (n2 < res->cap && res->p2_from && res->p2_to) { res->p2_from[n2] = from; res->p2_to[n2] = tov; } ++n2; }
+    }
+    res->n_p1 = n1; res->n_p2 = n2;
+    return DG_OK;
+}
+
+}  // namespace dgi
+
+extern "C" int dg_dp_load_graph(dg_ctx *c, const dg_dp_graph *g) {
+    if (int rc = dgi::bind(c)) return rc;
+    return dgi::dp_load(c, g);
+}
+extern "C" int dg_dp_run(dg_ctx *c, dg_dp_result *r) {
+    if (int rc = dgi::bind(c)) return rc;
+    return dgi::dp_run(c, r);
+}
+extern "C" int dg_dp_solve_diploid(dg_ctx *c, const dg_dp_graph *g, dg_dp_result *r) {
+    if (int rc = dg_dp_load_graph(c, g)) return rc;
+    return dg_dp_run(c, r);
+}
+extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
+    if (int rc = dgi::bind(c)) return rc;
+    if (!c->dp) c->dp = new dgi::DpState();
+    dgi::DpState &S = *c->dp;
+    if (S.pool.chunk_units != S.chunk_units_cfg) { dgi::pool_clear(S); S.pool.chunk_units = S.chunk_units_cfg; }
+    const size_t chunk_bytes = S.pool.chunk_units * 2;
+    if (S.pool.cap_chunks == 0) {          // first call only: later ones may arrive while chunks are being mapped
+        size_t free_b = 0, total_b = 0;
+        DG_HIP(hipMemGetInfo(&free_b, &total_b));
+        S.pool.cap_chunks = std::max<size_t>(1, (size_t)(0.6 * (double)free_b) / chunk_bytes);
+    }
+    const size_t want_chunks = bytes > 0 ? std::min(((size_t)bytes + chunk_bytes - 1) / chunk_bytes, S.pool.cap_chunks) : S.pool.cap_chunks;
+    dgi::pool_request(S, c->device, want_chunks);   // whole chunks; returns immediately
+    return DG_OK;
+}
+extern "C" int dg_dp_get_timing(dg_ctx *c, dg_dp_timing *t) {
+    if (!c || !c->dp || !t) { dgi::set_error("dg_dp_get_timing: no state"); return DG_ERR_STATE; }
+    *t = c->dp->timing;
+    return DG_OK;
+}
+extern "C" int dg_dp_get_level_digest(dg_ctx *c, uint64_t *out, int64_t n) {
+    if (!c || !c->dp || !out) { dgi::set_error("dg_dp_get_level_digest: no state"); return DG_ERR_STATE; }
+    if ((int64_t)c->dp->digest_host.size() != n) { dgi::set_error("digest not collected (set option digest=1) or size mismatch"); return DG_ERR_STATE; }
+    memcpy(out, c->dp->digest_host.data(), 8 * (size_t)n);
+    return DG_OK;
+}
+// Options: parity / test knobs (digest, fast, adaptive_rc, coop, rowx, segment_cells, delta_cap_entries, lattice_chunk_cells,
+// graph_batch, warm_ahead), profiler aid (sync_every), tuning (rc_*, bp_nt_min_cells, max_blocks, host_threads).
+extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
+    if (!c || !key) { dgi::set_error("dg_dp_set_option: null"); return DG_ERR_ARG; }
+    if (!c->dp) c->dp = new dgi::DpState();
+    dgi::DpState &S = *c->dp;
+    dgi::graphs_clear(S);
+    struct { const char *name; int64_t *field; int64_t lo; } plain[] = {
+        {"digest", &S.want_digest, 0}, {"fast", &S.use_fast, 0}, {"adaptive_rc", &S.adaptive_rc, 0}, {"coop", &S.use_coop, 0},
+        {"rowx", &S.use_rowx, 0},                                  // takes effect at the next load
+        {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
+        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1},
+        {"host_threads", &S.host_threads, 1},
+    };
+    for (auto &o : plain)
+        if (!strcmp(key, o.name)) { *o.field = v < o.lo ? o.lo : v; return DG_OK; }
+    if (!strcmp(key, "delta_cap_entries")) S.delta_cap_entries = v > 0 ? v : (int64_t)4 << 30;   // takes effect at the next load
+    else if (!strcmp(key, "rc_cap")) S.rc_cap = v > 0 ? v : 65536;
+    else if (!strcmp(key, "max_blocks")) S.max_blocks = v > 0 ? v : 1024;
+    else if (!strcmp(key, "lattice_chunk_cells")) {          // size of one lattice chunk (in 16-bit back-pointer units = cells on ordinary levels; default 2^32 = 8 GB)
+        if (v < 1) { dgi::set_error("lattice_chunk_cells must be positive"); return DG_ERR_ARG; }
+        dgi::pool_clear(S);
+        S.chunk_units_cfg = S.pool.chunk_units = ((size_t)v + 1) & ~(size_t)1;
+    }
+    else { dgi::set_error("unknown option %s", key); return DG_ERR_ARG; }
+    return DG_OK;
+}

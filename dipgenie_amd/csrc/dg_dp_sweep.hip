@@ -1,0 +1,562 @@
+// Level sweep of the diploid DP (approximator.cpp:627-701), edge-pair form.  State layout [i][r][j] (j fastest).
+//
+// The work of one transition is the T x T grid of in-edge pairs (e_u, e_v) -- exactly the index space of the delta
+// matrix.  One wave owns one task = (destination row i2, column group g, chunk of RC recombination counts): a group is
+// a run of <= 64 consecutive in-edges e_v that covers whole destination columns (host-built), so lane <-> e_v and
+// every destination cell's candidates sit in adjacent lanes.  The wave walks the row's in-edges e_u (wave-uniform),
+// and per step every lane does one delta load (coalesced along e_v) and RC value loads (coalesced along the source
+// column j) -- no per-lane inner loop, so a vertex with in-degree 24 costs 24 steps instead of 24 x 24.  Each lane
+// keeps, per recombination count, the best candidate as the pair (value, ord) with ord built from the in-edge ranks so
+// that a plain lexicographic max IS the reference's take-if order (value desc, pred_i asc, pred_j asc,
+// approximator.cpp:657-659).  A log-step segmented max over lanes of equal destination column finishes the cell; the
+// segment head stores the value and the back-pointer.
+#include <algorithm>
+#include <cmath>
+
+#include "dg_dp.hpp"
+
+namespace dgi {
+
+constexpr unsigned long long DIGEST_PRED_MUL = 0x9E3779B97F4A7C15ULL;   // oracle_dp.cpp: weight of the predecessor term
+
+__device__ __forceinline__ uint32_t ord_word(int i, int j, int wu, int wv) {
+    return ((uint32_t)(0x7FFF - i) << 17) | ((uint32_t)(0x7FFF - j) << 2) | ((uint32_t)wu << 1) | (uint32_t)wv;
+}
+__device__ __forceinline__ uint32_t bp_from_ord(uint32_t o) {
+    const uint32_t i = 0x7FFFu - (o >> 17), j = 0x7FFFu - ((o >> 2) & 0x7FFFu);
+    return i | (j << 15) | (((o >> 1) & 1u) << 30) | ((o & 1u) << 31);
+}
+// narrow form: ord = (255 - eu) << 8 | (255 - ev) is never 0 for a real candidate, and the stored back-pointer is
+// simply ~ord (an untouched best keeps ord 0 -> 0xFFFF = unreachable)
+// non-temporal 16-bit store as inline asm: with the builtin on one side of a branch and a plain store on the other the
+// optimiser merges the two into ONE plain store (the !nontemporal hint is dropped)
+__device__ __forceinline__ void store_bp_nt(uint16_t *p, uint32_t v) { asm volatile("global_store_short %0, %1, off nt" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t ord_rank(int eu, int ev) { return ((uint32_t)(BP_MAX_RANK - eu) << 8) | (uint32_t)(BP_MAX_RANK - ev); }
+
+// digest of one reachable cell: the oracle's definition (oracle_dp.cpp), o = its r-major cell index
+__device__ __forceinline__ unsigned long long digest_term(int value, unsigned long long o, uint32_t pred_i, uint32_t pred_j) {
+    return (unsigned long long)(uint32_t)(value + 1) * (o + 1) +
+           DIGEST_PRED_MUL * ((((unsigned long long)pred_i << 15) | pred_j) + 1ULL) * (o + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic form: group offsets read at run time; any in-degree, any level size, wide back-pointers
+// ---------------------------------------------------------------------------------------------
+template <int RC, bool DIGEST>
+__device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, int wave_id, int n_waves) {
+    const LevelDesc d = A.descs[lvl];
+    const int RP = A.RP;
+    const int32_t *__restrict__ cur = ((lvl - 1) & 1) ? A.buf1 : A.buf0;
+    int32_t *__restrict__ nxt = (lvl & 1) ? A.buf1 : A.buf0;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (RP + RC - 1) / RC;
+    const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
+    const bool has_delta = d.delta_off >= 0;
+    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
+    const int dT = has_delta ? d.T : 0, dmask = has_delta ? -1 : 0;
+    const uint32_t *gb = A.grp_begin + d.grp_first;
+    unsigned long long dsum = 0;
+    for (int64_t task = wave_id; task < ntask; task += n_waves) {
+        const int g = (int)(task % d.ngroups);
+        const int64_t rest = task / d.ngroups;
+        const int rc = (int)(rest % nchunk), i2 = (int)(rest / nchunk);
+        const int r0 = rc * RC;
+        const uint32_t gbeg = gb[g], gend = gb[g + 1];
+        const uint32_t eu0 = A.in_off[d.b0 + i2], eu1 = A.in_off[d.b0 + i2 + 1];
+        int bval[RC];
+        uint32_t bord[RC];
+#pragma unroll
+        for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+        int j2 = -1 - lane;                                             // inactive lanes: unique negative ids
+        // a group wider than 64 is one giant column (host guarantee): lanes accumulate over its chunks
+        for (uint32_t cb = gbeg; cb < gend; cb += 64) {
+            const uint32_t ev = cb + lane;
+            const bool act = ev < gend;
+            int j = 0, wv = 0, evr = 0;
+            if (act) {
+                const uint32_t pv = A.in_edge[ev];
+                j = (int)(pv & 0x7FFFFFFFu); wv = (int)(pv >> 31);
+                const int cv = A.in_dst[ev];
+                j2 = cv - d.b0;
+                if (!d.bp_wide) evr = (int)(ev - A.in_off[cv]);            // rank inside the column's in-edge list
+            }
+            const int dcol = (int)(ev - d.in_base) & dmask;
+            for (uint32_t eu = eu0; eu < eu1; ++eu) {
+                const uint32_t pu = A.in_edge[eu];
+                const int i = (int)(pu & 0x7FFFFFFFu), wu = (int)(pu >> 31);
+                if (act) {
+                    const int w = wu + wv;
+                    const int dl = (int)dm[(int64_t)(eu - d.in_base) * dT + dcol];
+                    const uint32_t ord = d.bp_wide ? ord_word(i, j, wu, wv) : ord_rank((int)(eu - eu0), evr);
+                    // rows r = r2 - w; the buffers carry front/tail padding so r = -1, -2 (and r2 >= RP in a
+                    // ragged last chunk) are legal reads that the select discards: RC loads back to back
+                    const int32_t *base = cur + ((int64_t)i * RP + (r0 - w)) * d.k + j;
+                    int vals[RC];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) vals[q] = base[q * d.k];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) {
+                        const int cand = vals[q] + dl;
+                        const bool ok = (r0 + q < RP) & (r0 + q - w >= 0) & (vals[q] != NEG_INF);       // :633, :646-647
+                        const bool take = ok & ((cand > bval[q]) | ((cand == bval[q]) & (ord > bord[q])));   // :657-659
+                        bval[q] = take ? cand : bval[q];
+                        bord[q] = take ? ord : bord[q];
+                    }
+                }
+            }
+        }
+        // segmented max over lanes with equal destination column (lanes of a column are adjacent)
+        const int span = (int)min(gend - gbeg, 64u);
+        for (int s = 1; s < span; s <<= 1) {
+            const int oj2 = __shfl_down(j2, s);
+            const bool same = (lane + s < 64) & (oj2 == j2);
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const int ov = __shfl_down(bval[q], s);
+                const uint32_t oo = (uint32_t)__shfl_down((int)bord[q], s);
+                const bool take = same & ((ov > bval[q]) | ((ov == bval[q]) & (oo > bord[q])));
+                bval[q] = take ? ov : bval[q];
+                bord[q] = take ? oo : bord[q];
+            }
+        }
+        const int pj2 = __shfl_up(j2, 1);
+        const bool head = (j2 >= 0) & ((lane == 0) | (pj2 != j2));
+        if (head) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const int r2 = r0 + q;
+                if (r2 < RP) {
+                    const int64_t idx = ((int64_t)i2 * RP + r2) * d.k2 + j2;
+                    nxt[idx] = bval[q];
+                    if (A.bp) {
+                        if (d.bp_wide) __builtin_nontemporal_store((uint32_t)(bval[q] == NEG_INF ? BP_NONE : bp_from_ord(bord[q])), (uint32_t *)(A.bp + d.bp_off + 2 * idx));
+                        else __builtin_nontemporal_store((uint16_t)~bord[q], &A.bp[d.bp_off + idx]);
+                    }
+                    if (DIGEST && bval[q] != NEG_INF) {
+                        const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
+                        uint32_t pi, pj;
+                        if (d.bp_wide) { const uint32_t h = bp_from_ord(bord[q]); pi = h & 0x7FFFu; pj = (h >> 15) & 0x7FFFu; }
+                        else {
+                            const uint32_t ru = BP_MAX_RANK - (bord[q] >> 8), rv = BP_MAX_RANK - (bord[q] & 0xFFu);
+                            pi = A.in_edge[eu0 + ru] & 0x7FFFFFFFu;
+                            pj = A.in_edge[A.in_off[d.b0 + j2] + rv] & 0x7FFFFFFFu;
+                        }
+                        dsum += digest_term(bval[q], o, pi, pj);
+                    }
+                }
+            }
+        }
+        // destination columns without any in-edge are unreachable: nobody owns them, clear them here
+        if (g == 0 && d.ndead > 0) {
+            for (int t = lane; t < d.ndead * RC; t += 64) {
+                const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
+                if (r0 + q < RP) {
+                    const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
+                    nxt[idx] = NEG_INF;
+                    if (A.bp) {
+                        if (d.bp_wide) __builtin_nontemporal_store((uint32_t)(BP_NONE), (uint32_t *)(A.bp + d.bp_off + 2 * idx));
+                        else __builtin_nontemporal_store((uint16_t)0xFFFFu, &A.bp[d.bp_off + idx]);
+                    }
+                }
+            }
+        }
+    }
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+}
+
+template <int RC, bool DIGEST>
+__global__ __launch_bounds__(256) void dp_sweep_kernel(SweepArgs A, int lvl) {
+    sweep_level_pairs<RC, DIGEST>(A, lvl, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), (int)(gridDim.x * 4));
+}
+
+__global__ void dp_init_kernel(int32_t *cur, int RP) {   // level 0: k = 1, every r starts at 0 (:534-535)
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r < RP) cur[r] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast form of the same sweep.  A level's kernel starts with cold caches (kernel boundary), so its
+// duration is a chain of dependent memory round trips (~0.5-1 us each) -- the fast form cuts the chain to
+//   kernel arguments (LevelDesc by value)  ->  {row record, slot record, row in-edge words}  ->  {delta, RC values}  ->  stores
+// * slot table: every column group is padded to exactly 64 records {j | wv<<15 | j2<<16, ev_local |
+//   rank<<20 | steps<<28}, so a lane finds its in-edge without reading group offsets;
+// * row record {first in-edge, in-degree, in-edge 0, in-edge 1} serves 97 % of the rows in one load;
+// * rows with more in-edges read them, one per lane, from the level's row in-edge matrix (LevelDesc::rowx_*) whose
+//   address needs no record -- the same load round -- and broadcast them with readlane; only levels without a matrix
+//   (in-degree > 64, or beyond the matrix budget) fetch the list from in_edge[] after the row record, one round later;
+// * the row's in-edges are processed U per step so U sets of RC loads are in flight;
+// * the segmented max runs only ceil(log2(max column in-degree of the group)) steps.
+// GENERAL variant (levels tagged fast_ok == 2): a column with in-degree > 64 (more than 64 haplotypes recombining into
+// one vertex) spans several slot blocks that one wave walks in turn, and rows of any in-degree fetch their in-edges 64
+// at a time.  Only sizes beyond the 3-D grid or 2^20 in-edges per level fall back to the generic kernel above.
+// COOP: 0 = every row; 1 = rows with more than COOP_MIN in-edges return (they are done by the cooperative region of
+// the same launch); 2 = cooperative: the four waves of the workgroup walk a quarter of the row's in-edges each, wave 0
+// merges the partial bests through LDS and finishes the task.
+// ---------------------------------------------------------------------------------------------
+
+// neighbour exchange by one lane as DPP wave shifts (a few cycles) instead of ds_bpermute (an LDS crossbar round trip):
+// most column groups need exactly one step of the segmented max (columns with at most two in-edges)
+__device__ __forceinline__ int lane_down1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1: lane i <- lane i + 1 */, 0xF, 0xF, false); }
+__device__ __forceinline__ int lane_up1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1: lane i <- lane i - 1 */, 0xF, 0xF, false); }
+
+template <int RC>
+__device__ __forceinline__ void relax_select(const int (&vals)[RC], int dl, uint32_t ord, int r0, int w, int RP,
+                                             int (&bval)[RC], uint32_t (&bord)[RC]) {
+#pragma unroll
+    for (int q = 0; q < RC; ++q) {
+        const int cand = vals[q] + dl;
+        const bool ok = (r0 + q < RP) & (r0 + q - w >= 0) & (vals[q] != NEG_INF);                   // :633, :646-647
+        const bool take = ok & ((cand > bval[q]) | ((cand == bval[q]) & (ord > bord[q])));           // :657-659
+        bval[q] = take ? cand : bval[q];
+        bord[q] = take ? ord : bord[q];
+    }
+}
+
+__device__ __forceinline__ void merge_best(int ov, uint32_t oo, bool same, int &bv, uint32_t &bo) {
+    const bool take = same & ((ov > bv) | ((ov == bv) & (oo > bo)));
+    bv = take ? ov : bv;
+    bo = take ? oo : bo;
+}
+
+template <int RC, bool DIGEST, bool GENERAL, int COOP>
+__device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const int RP = A.RP;
+    // first load round: every address below comes from kernel arguments and the block index alone
+    const uint4 rr = A.rowrec[d.b0 + i2];                               // {eu0, du, pu0, pu1}
+    uint2 sl = A.slots[d.slot_first + (int64_t)g * 64 + lane];
+    const bool rowx = !GENERAL && d.rowx_stride > 0;
+    uint32_t mypu = 0;                                                  // in-edge words of the row, one per lane
+    if (rowx && lane < d.rowx_stride) mypu = A.rowx[d.rowx_off + (int64_t)i2 * d.rowx_stride + lane];
+    // steps field: 0..6 = log2 steps of the segmented max; 15 = first block of a giant column (in-degree > 64: its
+    // in-edges fill several consecutive blocks, all walked by THIS wave); 14 = continuation block (nothing to do)
+    int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
+    const int j2 = (sl.x != 0xFFFFFFFFu) ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
+    int nblk = 1;
+    if (GENERAL) {
+        if (steps == 14) return;                                        // (workgroup-uniform in the cooperative region: same g)
+        if (steps == 15) {
+            const int col = __builtin_amdgcn_readfirstlane(j2);
+            nblk = ((int)A.rowrec[d.b0 + col].y + 63) >> 6;
+            steps = 6;
+        }
+    }
+    const bool has_delta = d.delta_off >= 0;
+    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
+    const int dT = has_delta ? d.T : 0;
+    const int du = (int)rr.y;
+    if (COOP == 1 && du > COOP_MIN) return;
+    const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;   // this wave's share of the row's in-edges
+    int bval[RC];
+    uint32_t bord[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+    const int64_t erow0 = (int64_t)(rr.x - d.in_base) * dT;
+    const int rowbytes = d.k * 4;
+    bool act = false;
+    // Source rows are r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
+    // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding; the select
+    // discards what is out of range, which lets every load be issued unconditionally, back to back.
+    for (int blk = 0; blk < (GENERAL ? nblk : 1); ++blk) {
+        if (GENERAL && blk > 0) sl = A.slots[d.slot_first + (int64_t)(g + blk) * 64 + lane];
+        const bool actb = sl.x != 0xFFFFFFFFu;
+        act |= actb;
+        const int j = (int)(sl.x & 0x7FFFu), wv = (int)((sl.x >> 15) & 1u);
+        const int dcol = has_delta ? (int)(sl.y & 0x000FFFFFu) : 0;
+        const int evr = (int)((sl.y >> 20) & 0xFFu);                   // rank of this lane's in-edge inside its column's list
+        if (du <= 2) {
+            // 97 % of the rows: both in-edges came with the row record, no loop, no extra load
+            if (actb && du > 0) {
+                const int ia = (int)(rr.z & 0x7FFFu), wa = (int)(rr.z >> 31) + wv;    // (bit 16: flag for the chain walk)
+                const int ib = (int)(rr.w & 0x7FFFu), wb = (int)(rr.w >> 31) + wv;
+                const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
+                const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
+                int va[RC], vb[RC];
+                const int dla = (int)dm[erow0 + dcol];
+                int dlb = 0;
+#pragma unroll
+                for (int q = 0; q < RC; ++q) va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offa + q * rowbytes, 0, 0);
+                if (du == 2) {
+                    dlb = (int)dm[erow0 + dT + dcol];
+#pragma unroll
+                    for (int q = 0; q < RC; ++q) vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, 0);
+                }
+                relax_select<RC>(va, dla, ord_rank(0, evr), r0, wa, RP, bval, bord);
+                if (du == 2) relax_select<RC>(vb, dlb, ord_rank(1, evr), r0, wb, RP, bval, bord);
+            }
+        } else {
+            // heavy rows (recombination fan-in): U in-edges per step -- all their loads (U deltas + U*RC values) go out
+            // back to back, then the selects run; (value, ord) max is associative and commutative, so the order inside
+            // a step is irrelevant.  Small RC leaves registers for a deep step: in-degree 23 takes 2 steps at RC = 1.
+            constexpr int U = GENERAL ? (RC >= 4 ? 2 : 4) : (RC >= 8 ? 2 : (RC >= 4 ? 4 : 8));
+            // lean variant: one trip (in-degree <= 64, lane t of mypu = in-edge t); general: 64 in-edges per trip
+            for (int c0 = GENERAL ? t_lo : 0; c0 < t_hi; c0 += GENERAL ? 64 : (1 << 30)) {
+                const int tb = GENERAL ? c0 : t_lo, te = GENERAL ? min(c0 + 64, t_hi) : t_hi;
+                if (!rowx) { mypu = 0; if (c0 + lane < te) mypu = A.in_edge[rr.x + c0 + lane]; }
+                for (int t = tb; t < te; t += U) {
+                    // the in-edge words live in SGPRs only until the load offset is formed; the select needs just their
+                    // weight bits, kept in one mask (a deep step would otherwise hold U scalars and spill)
+                    uint32_t wmask = 0;
+                    if (actb) {
+                        int vals[U][RC], dl[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (t + u < te) {                                 // wave-uniform
+                                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mypu, t + u - c0);
+                                wmask |= (p >> 31) << u;
+                                const int iu = (int)(p & 0x7FFFFFFFu), w = (int)(p >> 31) + wv;
+                                const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
+                                dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
+#pragma unroll
+                                for (int q = 0; q < RC; ++q) vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, off + q * rowbytes, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (t + u < te) {
+                                const int wu = (int)((wmask >> u) & 1u);
+                                relax_select<RC>(vals[u], dl[u], ord_rank(t + u, evr), r0, wu + wv, RP, bval, bord);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (COOP == 2) {                                                    // partial bests of waves 1..3 -> wave 0
+        if (part > 0) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) ex[((part - 1) * RC + q) * 64 + lane] = make_uint2((uint32_t)bval[q], bord[q]);
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = 0; q < RC; ++q) {
+                const uint2 o = ex[(p * RC + q) * 64 + lane];
+                merge_best((int)o.x, o.y, true, bval[q], bord[q]);
+            }
+        }
+    }
+    // segmented max over lanes with equal destination column (lanes of a column are adjacent)
+    if (steps > 0) {                                                    // first step: distance 1, DPP
+        const int oj2 = lane_down1(j2);
+        const bool same = (lane + 1 < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) merge_best(lane_down1(bval[q]), (uint32_t)lane_down1((int)bord[q]), same, bval[q], bord[q]);
+    }
+    for (int st = 1, sh = 2; st < steps; ++st, sh <<= 1) {
+        const int oj2 = __shfl_down(j2, sh);
+        const bool same = (lane + sh < 64) & (oj2 == j2);
+#pragma unroll
+        for (int q = 0; q < RC; ++q) merge_best(__shfl_down(bval[q], sh), (uint32_t)__shfl_down((int)bord[q], sh), same, bval[q], bord[q]);
+    }
+    const int pj2 = lane_up1(j2);
+    const bool head = act & ((lane == 0) | (pj2 != j2));
+    unsigned long long dsum = 0;
+    if (head) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int r2 = r0 + q;
+            if (r2 < RP) {
+                const int idx = (i2 * RP + r2) * d.k2 + j2;            // fast form: a state buffer is < 2 GB, 32-bit indices
+                nxt[idx] = bval[q];
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
+                if (DIGEST && bval[q] != NEG_INF) {                    // (parity runs only: the extra loads are off the product path)
+                    const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
+                    const uint32_t ru = BP_MAX_RANK - (bord[q] >> 8), rv = BP_MAX_RANK - (bord[q] & 0xFFu);
+                    const uint32_t pi = A.in_edge[rr.x + ru] & 0x7FFFFFFFu;
+                    const uint32_t pj = A.in_edge[A.rowrec[d.b0 + j2].x + rv] & 0x7FFFFFFFu;
+                    dsum += digest_term(bval[q], o, pi, pj);
+                }
+            }
+        }
+    }
+    if (g == 0 && d.ndead > 0) {                                        // columns nobody owns: unreachable
+        for (int t = lane; t < d.ndead * RC; t += 64) {
+            const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
+            if (r0 + q < RP) {
+                const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
+                nxt[idx] = NEG_INF;
+                if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], 0xFFFFu); else A.bp[d.bp_off + idx] = (uint16_t)0xFFFFu; }
+            }
+        }
+    }
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padded_base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)padded_base, 0, bytes, 0x00020000);
+}
+
+// per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2 [+ 4 per heavy row]), one task per wave (a 3-D
+// grid: splitting a combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
+template <int RC, bool DIGEST, bool GENERAL, bool COOP = false>
+__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl, const int32_t *__restrict__ heavy_rows = nullptr) {
+    const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
+    int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
+    if (COOP && (int)blockIdx.z >= d.k2) {
+        // cooperative region (blockDim = 4 waves): workgroup (x, y, k2 + 4 h + b) = slot block 4 x + b of the h-th heavy row
+        __shared__ uint2 ex[3 * RC * 64];
+        const int hz = (int)blockIdx.z - d.k2;
+        const int g = (int)blockIdx.x * 4 + (hz & 3);
+        if (g >= d.nblocks) return;                                     // workgroup-uniform: nobody is left at the barrier
+        const int h = hz >> 2;
+        int i2;                                                         // the first heavy rows ride in the kernel arguments: no dependent load
+        switch (h) {
+            case 0: i2 = d.heavy_in[0]; break; case 1: i2 = d.heavy_in[1]; break; case 2: i2 = d.heavy_in[2]; break; case 3: i2 = d.heavy_in[3]; break;
+            case 4: i2 = d.heavy_in[4]; break; case 5: i2 = d.heavy_in[5]; break; case 6: i2 = d.heavy_in[6]; break; case 7: i2 = d.heavy_in[7]; break;
+            default: i2 = heavy_rows[d.heavy_first + h]; break;
+        }
+        sweep_task<RC, DIGEST, GENERAL, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, (int)(threadIdx.x >> 6), ex);
+        return;
+    }
+    const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
+    const int i2 = (int)blockIdx.z;
+    sweep_task<RC, DIGEST, GENERAL, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+}
+
+// Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
+// levels through the memory-side Infinity Cache.  Every table byte is read exactly once per pass, so without this each
+// level's two dependent load rounds go all the way to HBM; the batch is a few MB, read at full chip bandwidth.
+constexpr int WARM_RANGES = 5;
+struct WarmRanges { const char *p[WARM_RANGES]; long long n16[WARM_RANGES]; };   // start (16-byte aligned down) and length in 16-byte units
+__global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int q = 0; q < WARM_RANGES; ++q) {
+        const uint4 *p = (const uint4 *)W.p[q];
+        for (long long i = tid; i < W.n16[q]; i += nth) { uint4 v = p[i]; asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void sweep_prepare(const DpState &S, SweepLaunch &X) {
+    X.rc_sel = S.RP <= 8 ? 8 : (S.RP <= 19 ? 19 : 33);
+    X.small_state = S.state_alloc_bytes < ((size_t)1 << 31);            // 32-bit buffer offsets
+    SweepArgs &A = X.A;
+    A.descs = S.d_descs.as<LevelDesc>(); A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
+    A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
+    A.delta = A.delta_zero = S.d_delta.as<uint16_t>();
+    A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
+    A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
+    FastArgs &F = X.F;
+    F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.rowx = S.d_rowx.as<uint32_t>(); F.dead_cols = A.dead_cols;
+    F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
+    F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
+    F.pad_bytes = (int)(4 * S.pad_front);
+    F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
+}
+
+void sweep_init_state(const DpState &S, hipStream_t s) {
+    hipLaunchKernelGGL(dp_init_kernel, dim3((unsigned)((S.RP + 255) / 256)), dim3(256), 0, s, S.d_val[0].as<int32_t>() + S.pad_front, S.RP);
+}
+
+// A lone wave retires ~1 instruction per 4-8 cycles, so an RC-fold unrolled task is the level's critical path: while
+// the chip has idle wave slots, give each wave fewer recombination counts.  Cost model fitted on MHC-24 (R = 18) and
+// the 100-walk chr22-style panel (R = 32):
+//   T(RC) = max(1, W / cap) * (t0 + dmax * RC * tg) + W * tw,   W = tasks * ceil(RP / RC) waves.
+// First factor: rounds of resident waves; second: a wave's dependent chain (the row with the largest in-degree walks
+// dmax in-edges with RC gathers each); last: per-wave issue overhead.  Cooperative variant (RC <= 4): rows above
+// COOP_MIN in-edges are walked by four waves, so the chain is a quarter (at least COOP_MIN) while four extra
+// workgroup slots per heavy row are launched.
+static void choose_rc(const DpState &S, const LevelDesc &d, int l, int rc_sel, int &rc, bool &coop) {
+    rc = rc_sel;
+    coop = false;
+    if (S.adaptive_rc == 0) return;
+    const int cand[11] = {1, 2, 3, 4, 5, 6, 8, 10, 11, 16, rc_sel};
+    const bool coop_ok = S.use_coop && d.n_heavy > 0 && d.k2 + 4 * d.n_heavy <= 65535;
+    const double dmax = (double)std::max(1, S.level_dmax[l]);
+    double best = 1e300;
+    for (int pass = (coop_ok && S.use_coop == 2) ? 1 : 0; pass < (coop_ok ? 2 : 1); ++pass) {     // coop = 2 (tests): whenever possible
+        for (int q = 0; q < 11; ++q) {
+            if (cand[q] > rc_sel || (q < 10 && cand[q] == rc_sel)) continue;
+            if (pass == 1 && cand[q] > 4) continue;
+            const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
+            const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
+            const double W = rows * d.nblocks * ((S.RP + cand[q] - 1) / cand[q]);
+            const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + chain * cand[q] * (double)S.rc_tg_ps * 1e-3) + W * (double)S.rc_tw_ps * 1e-3;
+            if (T <= best) { best = T; rc = cand[q]; coop = pass == 1; }   // ties: the larger RC (fewer waves)
+        }
+    }
+}
+
+void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
+    LevelDesc &d = S.descs[l];
+    // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
+    // non-temporal ones that keep the once-written lattice out of the L2
+    d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
+    if (d.fast_ok && X.small_state && S.RP <= 65535 && S.use_fast) {
+        int rc;
+        bool coop;
+        choose_rc(S, d, l, X.rc_sel, rc, coop);
+        const int nch = (S.RP + rc - 1) / rc;
+        const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
+        const int32_t *hv = S.d_heavy.as<int32_t>();
+        const FastArgs &F = X.F;
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
+#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
+#define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
+                                                    default: DG_COOP(4, DG); break; } break; } \
+                            switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
+                                        case 4: DG_FAST(4, DG); break; case 5: DG_FAST(5, DG); break; case 6: DG_FAST(6, DG); break; \
+                                        case 8: DG_FAST(8, DG); break; case 10: DG_FAST(10, DG); break; case 11: DG_FAST(11, DG); break; \
+                                        case 16: DG_FAST(16, DG); break; case 19: DG_FAST(19, DG); break; \
+                                        default: DG_FAST(33, DG); break; } } while (0)
+        if (S.want_digest) DG_FAST_RC(true); else DG_FAST_RC(false);
+#undef DG_COOP
+#undef DG_FAST_RC
+#undef DG_FAST
+    } else {
+        const int nchunk = (S.RP + X.rc_sel - 1) / X.rc_sel;
+        const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
+        const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
+        const SweepArgs &A = X.A;
+#define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
+        if (S.want_digest) { if (X.rc_sel == 8) DG_SWEEP(8, true); else if (X.rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
+        else { if (X.rc_sel == 8) DG_SWEEP(8, false); else if (X.rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }
+#undef DG_SWEEP
+    }
+}
+
+void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s) {   // graph tables of destination levels [q0, q1) -> Infinity Cache
+    const LevelDesc &da = S.descs[q0], &db = S.descs[q1 - 1];
+    const FastArgs &F = X.F;
+    WarmRanges W{};
+    auto put = [&](int q, const void *base, int64_t b0, int64_t b1) {       // byte range [b0, b1) behind base
+        const uintptr_t a = ((uintptr_t)base + (uintptr_t)b0) & ~(uintptr_t)15, e = ((uintptr_t)base + (uintptr_t)b1) & ~(uintptr_t)15;
+        W.p[q] = (const char *)a; W.n16[q] = e > a ? (long long)((e - a) >> 4) : 0;
+    };
+    put(0, F.rowrec, 16 * (int64_t)da.b0, 16 * ((int64_t)db.b0 + db.k2));
+    put(1, F.slots, 8 * da.slot_first, 8 * (db.slot_first + (int64_t)db.nblocks * 64));
+    put(2, F.in_edge, 4 * (int64_t)da.in_base, 4 * ((int64_t)db.in_base + db.T));
+    int64_t d0 = -1, d1 = -1, x0 = -1, x1 = -1;
+    for (int q = q0; q < q1; ++q) {
+        const LevelDesc &dq = S.descs[q];
+        if (dq.rowx_stride > 0) {                                           // (matrices are laid out in level order)
+            if (x0 < 0) x0 = dq.rowx_off;
+            x1 = dq.rowx_off + (int64_t)dq.k2 * dq.rowx_stride;
+        }
+        if (dq.delta_off < 0 || S.level_win[q] != S.cur_win) continue;
+        const int64_t e = dq.delta_off + (int64_t)dq.T * dq.T;
+        d0 = d0 < 0 ? dq.delta_off : std::min(d0, dq.delta_off);
+        d1 = std::max(d1, e);
+    }
+    if (d0 >= 0) put(3, F.delta, 2 * d0, 2 * d1);
+    if (x0 >= 0) put(4, F.rowx, 4 * x0, 4 * x1);
+    long long tot = 0;
+    for (int q = 0; q < WARM_RANGES; ++q) tot += W.n16[q];
+    if (tot <= 0) return;
+    const unsigned grid = (unsigned)std::min<long long>((tot + 255) / 256, 2048);
+    hipLaunchKernelGGL(dp_warm_tables_kernel, dim3(grid), dim3(256), 0, s, W);
+}
+
+}  // namespace dgi

@@ -1,0 +1,201 @@
+// Traceback of the diploid DP (approximator.cpp:757-785).
+// Chain kernel (one wave): walk the back-pointer lattice downwards from a known cell.  The chain is one dependent HBM
+// load per level, so everything else is kept off it: the level descriptors of the next 64 levels are fetched one per
+// lane and broadcast with readlane, and the hop words are parked in path[].  In segmented mode it is called once per
+// chunk, last chunk first, carrying the cell in ChainState.
+// Finish kernel (1024 threads, levels in parallel): re-derive s_het from the colour lists of the winning edge pairs
+// (:662) and emit the weighted edges (:673-692; both final edges unconditionally) as (level, from, to, which) records;
+// the host orders them by level.
+#include <algorithm>
+
+#include "dg_dp_setops.hpp"
+
+namespace dgi {
+
+// Pulls the row records of a range of levels into the memory-side Infinity Cache right before the chain walk reads two
+// of them per level (they were last touched by the sweep, hundreds of GB of lattice writes ago).
+__global__ __launch_bounds__(256) void dp_warm_kernel(const uint4 *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { uint4 v = p[i]; asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+}
+
+// Speculative chain walk.  A plain step (load the back-pointer, decode, move) costs one HBM round trip because the next
+// cell's address needs this level's back-pointer.  But the candidates are few: with at most two in-edges into the row
+// and into the column (97 % of the vertices) the predecessor is one of four cells, all known as soon as the two row
+// records are in.  Lanes 0..3 (mirrored by the other lanes) therefore load the back-pointer AND the row records of
+// "their" candidate one level ahead; when this level's back-pointer arrives it only selects the lane whose loads are
+// already in flight, so two levels' HBM round trips overlap.  A rank above 1 or a wide level resolves the predecessor
+// with extra loads and re-issues exact loads for it.
+// Shape of the code (it matters: the compiler derives its s_waitcnt from it): every path through a step ends with the
+// three loads (row record, column record, back-pointer word) of the next level as the most recent memory operations, and
+// a step consumes only what the previous step issued; the step is instantiated twice with the two register sets swapped,
+// because copying a register that still has a load in flight would wait for that load.
+struct ChainWalk {
+    int i, j, r, value, csel;
+};
+struct ChainRegs { uint4 row, col; uint32_t b; };
+struct ChainDesc { long long bo; int k2, bw, kp; };    // bp offset, width, first vertex | wide << 31, source width
+
+// loads of one cell (level descriptor bo/k2/bw): row records + the aligned 32-bit word that holds its back-pointer
+__device__ __forceinline__ void chain_issue(ChainRegs &Y, const uint16_t *__restrict__ bp, const uint4 *__restrict__ rowrec, long long bo, int k2, int bw,
+                                            int RP, int ci, int cj, int cr) {
+    const int b0 = bw & 0x7FFFFFFF;
+    const long long unit = bo + (((long long)ci * RP + cr) * k2 + cj) * (bw < 0 ? 2 : 1);
+    Y.row = rowrec[b0 + ci];
+    Y.col = rowrec[b0 + cj];
+    Y.b = *(const uint32_t *)(bp + (unit & ~1LL));
+}
+
+__device__ __forceinline__ void chain_spec_step(ChainWalk &W, int l, int l_lo, int RP, const ChainDesc &D, const ChainDesc &N,
+                                                const uint16_t *__restrict__ bp, const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
+                                                uint32_t &hops, int slot, int lane, ChainRegs &X, ChainRegs &Y) {
+    const int ca = lane & 1, cb = (lane >> 1) & 1;                      // this lane's candidate: rank ca of the row, cb of the column
+    const long long bo_l = D.bo, nbo = N.bo;
+    const int k2 = D.k2, bw = D.bw, kprev = D.kp, nk2 = N.k2, nbw = N.bw;
+    const int cs = W.csel;
+    const uint32_t rix = (uint32_t)__builtin_amdgcn_readlane((int)X.row.x, cs), riy = (uint32_t)__builtin_amdgcn_readlane((int)X.row.y, cs);
+    const uint32_t riz = (uint32_t)__builtin_amdgcn_readlane((int)X.row.z, cs), riw = (uint32_t)__builtin_amdgcn_readlane((int)X.row.w, cs);
+    const uint32_t rjx = (uint32_t)__builtin_amdgcn_readlane((int)X.col.x, cs), rjy = (uint32_t)__builtin_amdgcn_readlane((int)X.col.y, cs);
+    const uint32_t rjz = (uint32_t)__builtin_amdgcn_readlane((int)X.col.z, cs), rjw = (uint32_t)__builtin_amdgcn_readlane((int)X.col.w, cs);
+    // one level ahead: the four candidate cells of level l - 1; a lane without a valid candidate re-reads this level's cell
+    const bool have_next = l - 1 >= l_lo;
+    const uint32_t wa = ca ? riw : riz, wb = cb ? rjw : rjz;
+    const int ci = (int)(wa & 0x7FFFu), cj = (int)(wb & 0x7FFFu), cr = W.r - (int)(wa >> 31) - (int)(wb >> 31);
+    const bool ok = have_next & ((uint32_t)ca < riy) & ((uint32_t)cb < rjy) & (cr >= 0) & (ci < kprev) & (cj < kprev);
+    chain_issue(Y, bp, rowrec, ok ? nbo : bo_l, ok ? nk2 : k2, ok ? nbw : bw, RP, ok ? ci : W.i, ok ? cj : W.j, ok ? cr : W.r);
+    // this level's back-pointer word (issued one step ago)
+    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)X.b, cs);
+    uint32_t hop;
+    bool exact_next = false;                                            // the predecessor is not among the candidates in flight
+    if (bw < 0) {                                                       // wide level: the word is the hop
+        hop = word;
+        exact_next = true;
+    } else {
+        const long long unit = bo_l + ((long long)W.i * RP + W.r) * k2 + W.j;
+        const uint32_t bv = (unit & 1) ? (word >> 16) : (word & 0xFFFFu);
+        const uint32_t eu = bv >> 8, ev = bv & 0xFFu;
+        if (eu >= riy || ev >= rjy) { W.value = CHAIN_CORRUPT; W.i = W.j = 0; W.r = 0; return; }   // (0xFFFF = unreachable lands here too)
+        const uint32_t pu = eu == 0 ? riz : (eu == 1 ? riw : in_edge[rix + eu]);
+        const uint32_t pv = ev == 0 ? rjz : (ev == 1 ? rjw : in_edge[rjx + ev]);
+        hop = (pu & 0x7FFFu) | ((pv & 0x7FFFu) << 15) | ((pu >> 31) << 30) | ((pv >> 31) << 31);
+        exact_next = (eu > 1) | (ev > 1);
+        W.csel = (int)((eu & 1u) | ((ev & 1u) << 1));
+    }
+    hops = lane == slot ? hop : hops;                                   // lane t keeps the hop of the batch's t-th level: one store per batch,
+    W.i = (int)(hop & 0x7FFFu); W.j = (int)((hop >> 15) & 0x7FFFu);     // none inside the walk (stores share the loads' counter)
+    W.r -= (int)((hop >> 30) & 1u) + (int)(hop >> 31);
+    // a hop that leaves the source level means the lattice is corrupt (a level nobody swept): stop before the next
+    // load goes wild -- the host reports DG_ERR_STATE instead of the GPU faulting
+    if ((W.i >= kprev) | (W.j >= kprev) | (W.r < 0)) { W.value = CHAIN_CORRUPT; W.i = W.j = 0; W.r = 0; return; }
+    if (have_next && (exact_next || nbw < 0)) {                         // rare: exact loads of the predecessor replace the candidates
+        chain_issue(Y, bp, rowrec, nbo, nk2, nbw, RP, W.i, W.j, W.r);
+        W.csel = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
+                                                                 const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
+                                                                 const int32_t *__restrict__ final_val /* non-null on the first call */,
+                                                                 const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
+                                                                 uint32_t *__restrict__ path, ChainState *st) {
+    const int lane = threadIdx.x & 63;
+    ChainWalk W;
+    W.csel = 0;
+    if (final_val) { W.value = final_val[(int64_t)R * descs[l_hi].k2]; W.i = 0; W.j = 0; W.r = R; }   // sink level, layout [i][r][j]: cell (0, R, 0)
+    else { W.i = st->i; W.j = st->j; W.r = st->r; W.value = st->value; }
+    if (W.value != NEG_INF && W.value != CHAIN_CORRUPT) {
+        ChainRegs A, B;
+        bool first = true;
+        for (int base = l_hi; base >= l_lo && W.value != CHAIN_CORRUPT; base -= 56) {
+            const int my_l = base - lane;                               // 64 descriptors, 56 levels (a multiple of 8) per batch
+            long long bo = 0;
+            int kk = 1, bb = 0, kp = 1;                                 // bb = first vertex of the level | wide << 31; kp = source width
+            if (my_l >= l_lo) { bo = descs[my_l].bp_off; kk = descs[my_l].k2; kp = descs[my_l].k; bb = descs[my_l].b0 | (descs[my_l].bp_wide << 31); }
+            asm volatile("" ::"v"(bo), "v"(kk), "v"(bb), "v"(kp));      // descriptors complete before the walk (no wait inside the loop)
+            const int n = min(56, base - l_lo + 1);
+            uint32_t hops = 0;
+#define DG_DESC(T) ChainDesc{((long long)__builtin_amdgcn_readlane((int)(bo >> 32), (T)) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)bo, (T)), \
+                            __builtin_amdgcn_readlane(kk, (T)), __builtin_amdgcn_readlane(bb, (T)), __builtin_amdgcn_readlane(kp, (T))}
+            ChainDesc D0 = DG_DESC(0), D1;                              // descriptor of the level at hand / one level ahead, rotated like the registers
+            if (first) {                                                // prologue: exact loads of the starting cell
+                chain_issue(A, bp, rowrec, D0.bo, D0.k2, D0.bw, RP, W.i, W.j, W.r);
+                first = false;
+            }
+            // unrolled by hand (8 steps per trip): the loop's back edge copies the registers of the loads in flight, and so
+            // waits for them -- one un-overlapped step per trip
+#define DG_CHAIN_STOP(T) (W.value == CHAIN_CORRUPT || (T) >= n)
+#define DG_CHAIN_STEP(T, X, Y, DC, DN) DN = DG_DESC((T) + 1); chain_spec_step(W, base - (T), l_lo, RP, DC, DN, bp, rowrec, in_edge, hops, (T), lane, X, Y)
+            for (int t = 0; t < n; t += 8) {
+                DG_CHAIN_STEP(t, A, B, D0, D1);     if (DG_CHAIN_STOP(t + 1)) break;
+                DG_CHAIN_STEP(t + 1, B, A, D1, D0); if (DG_CHAIN_STOP(t + 2)) break;
+                DG_CHAIN_STEP(t + 2, A, B, D0, D1); if (DG_CHAIN_STOP(t + 3)) break;
+                DG_CHAIN_STEP(t + 3, B, A, D1, D0); if (DG_CHAIN_STOP(t + 4)) break;
+                DG_CHAIN_STEP(t + 4, A, B, D0, D1); if (DG_CHAIN_STOP(t + 5)) break;
+                DG_CHAIN_STEP(t + 5, B, A, D1, D0); if (DG_CHAIN_STOP(t + 6)) break;
+                DG_CHAIN_STEP(t + 6, A, B, D0, D1); if (DG_CHAIN_STOP(t + 7)) break;
+                DG_CHAIN_STEP(t + 7, B, A, D1, D0); if (DG_CHAIN_STOP(t + 8)) break;
+            }
+#undef DG_CHAIN_STOP
+#undef DG_CHAIN_STEP
+#undef DG_DESC
+            if (lane < n && W.value != CHAIN_CORRUPT) path[base - lane] = hops;
+        }
+    }
+    if (lane == 0) { st->i = W.i; st->j = W.j; st->r = W.r; st->value = W.value; }
+}
+
+__global__ __launch_bounds__(1024) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
+                                                               ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
+                                                               const ChainState *st, TraceOut *out) {
+    __shared__ int s_shet, s_ne;
+    if (threadIdx.x == 0) { s_shet = 0; s_ne = 0; }
+    __syncthreads();
+    const int value = st->value;
+    if (value != NEG_INF && value != CHAIN_CORRUPT) {
+        int shet = 0;
+        for (int l = 1 + (int)threadIdx.x; l < L; l += (int)blockDim.x) {
+            const uint32_t b = path[l];
+            int i = 0, j = 0;                                         // destination cell at level l = predecessor recorded at l+1
+            if (l < L - 1) { const uint32_t nb = path[l + 1]; i = (int)(nb & 0x7FFFu); j = (int)((nb >> 15) & 0x7FFFu); }
+            const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
+            const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
+            const LevelDesc d = descs[l];
+            const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
+            if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
+            const int reps = (l == L - 1) ? 1 : 0;
+            for (int q = 0; q < reps + wu; ++q) {
+                const int e = atomicAdd(&s_ne, 1);
+                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = u1; edges[2 * cap_e + e] = u2; edges[3 * cap_e + e] = 0; }
+            }
+            for (int q = 0; q < reps + wv; ++q) {
+                const int e = atomicAdd(&s_ne, 1);
+                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = v1; edges[2 * cap_e + e] = v2; edges[3 * cap_e + e] = 1; }
+            }
+        }
+        if (shet) atomicAdd(&s_shet, shet);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TraceOut o;
+        o.value = value; o.s_het = s_shet; o.n_e = s_ne; o.overflow = s_ne > cap_e ? 1 : 0;
+        *out = o;
+    }
+}
+
+void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {   // row records of destination levels [lb, le), at most ~200 MB worth
+    const int64_t v0 = S.descs[lb].b0, v1 = (int64_t)S.descs[le - 1].b0 + S.descs[le - 1].k2;
+    const int64_t n = std::min<int64_t>(v1 - v0, (int64_t)12 << 20);
+    if (n > 0) hipLaunchKernelGGL(dp_warm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S.d_rowrec.as<uint4>() + (v1 - n), n);
+}
+
+void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s) {
+    hipLaunchKernelGGL(dp_trace_chain_spec_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
+                       S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+}
+
+void trace_launch_finish(const DpState &S, hipStream_t s) {
+    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3(1), dim3(1024), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_path.as<uint32_t>(), colour_csr(S), S.cap,
+                       S.d_edges.as<int32_t>(), S.d_chain.as<ChainState>(), S.d_trace.as<TraceOut>());
+}
+
+}  // namespace dgi

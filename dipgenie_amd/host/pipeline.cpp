@@ -1030,9 +1030,11 @@ int Pipeline::solve(std::string &err) {
         std::string out;
         for (auto u : dp_path) out += node_seq[u];
         std::ofstream f(opt.hap_file, std::ios::out);
+        if (!f.is_open()) { err = "cannot open output file " + opt.hap_file; return -1; }
         f << ">" << "dp_sol" << " LN:" << out.size() << std::endl;
         for (size_t i = 0; i < out.size(); i += 80) f << out.substr(i, 80) << std::endl;
         f.close();
+        if (!f.good()) { err = "write to " + opt.hap_file + " failed"; return -1; }
         sum.len1 = (int64_t)out.size();
         stamp("haploid_dp+write", t0);
     } else {
@@ -1230,8 +1232,10 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
             for (size_t i = 0; i < hap_seq[q].size(); i += 80) { text.append(hap_seq[q], i, 80); text += '\n'; }
         }
         std::ofstream f(opt.hap_file, std::ios::out | std::ios::binary);
+        if (!f.is_open()) { err = "cannot open output file " + opt.hap_file; return -1; }
         f.write(text.data(), (std::streamsize)text.size());
         f.close();
+        if (!f.good()) { err = "write to " + opt.hap_file + " failed"; return -1; }
     }
     stamp("traceback+write", t0);
     return 0;
@@ -1239,8 +1243,9 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
 
 int Pipeline::run(std::string &err) {                                  // main.cpp:117-165
     sum = Summary();
+    opt.threads = std::max(1, opt.threads);                            // -t0 / negative: every num_threads clause below sees a valid count
 #ifdef _OPENMP
-    omp_set_num_threads(std::max(1, opt.threads));
+    omp_set_num_threads(opt.threads);
 #endif
     double t0 = now_s();
     if (load_graph(err)) return -1;

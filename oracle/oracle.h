@@ -62,7 +62,9 @@ typedef struct orc_dp_result {
 /* Literal single-thread restatement of the level loop approximator.cpp:532-716 (scatter form,
  * loop order r,i,j, adjacency order, take-if rule :657-659) and of the sink read-out :774-785.
  * If level_digest != NULL it receives one uint64 per level l=1..L-1 (index l): a digest of
- * dp_cur after the roll, = sum over reachable cells of (value+1)*(cell_index+1) mod 2^64. */
+ * dp_cur after the roll, = sum over reachable cells (cell_index t, r-major) of
+ *   (value+1)*(t+1) + 0x9E3779B97F4A7C15 * ((pred_i << 15 | pred_j) + 1)*(t+1)   mod 2^64,
+ * i.e. it pins the value AND the winning predecessor (tie-break :657-659) of every cell. */
 int      orc_dp_solve_diploid(const orc_dp_graph *g, orc_dp_result *res, uint64_t *level_digest);
 
 /* inter_size_union2x2 / symdiff_size_union2x2 (approximator.cpp:269-311) on sorted int lists */

@@ -196,7 +196,9 @@ extern "C" int orc_dp_solve_diploid(const orc_dp_graph *g, orc_dp_result *res, u
         if (level_digest) {
             uint64_t d = 0;
             for (size_t t = 0; t < cur.size(); ++t)
-                if (cur[t].value != NEG_INF) d += (uint64_t)(uint32_t)(cur[t].value + 1) * (uint64_t)(t + 1);
+                if (cur[t].value != NEG_INF)                         // value term + predecessor term (the :657-659 tie-break of EVERY cell)
+                    d += (uint64_t)(uint32_t)(cur[t].value + 1) * (uint64_t)(t + 1) +
+                         0x9E3779B97F4A7C15ULL * ((((uint64_t)cur[t].pred_i << 15) | (uint64_t)cur[t].pred_j) + 1ULL) * (uint64_t)(t + 1);
             level_digest[l + 1] = d;
         }
     }

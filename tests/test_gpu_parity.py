@@ -131,11 +131,11 @@ def test_dp_random_levelized(gpu_ctx, seed):
     _dp_both(gpu_ctx, g)
 
 
-@pytest.mark.parametrize("mode", ["generic", "team", "no_adaptive", "budget_rc", "model_rc_pow2", "no_coop", "force_coop"])
+@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
-    """the generic fallback sweep, the one-XCD team kernel and the fixed-RC launch must all give the oracle's answer"""
-    opts = {"generic": {"fast": 0}, "team": {"team": 1, "team_min_levels": 4, "team_max_tasks": 4096}, "no_adaptive": {"adaptive_rc": 0},
-            "budget_rc": {"adaptive_rc": 1}, "model_rc_pow2": {"adaptive_rc": 2}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}}[mode]
+    """the generic fallback sweep, the fixed-RC launch, cooperative rows off / forced and the path without row in-edge
+    matrices must all give the oracle's answer"""
+    opts = {"generic": {"fast": 0}, "no_adaptive": {"adaptive_rc": 0}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}, "no_rowx": {"rowx": 0}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -145,13 +145,19 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             out = gpu_ctx.dp_solve(g)
             ref = orc.dp_solve(g)
             assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"]), (mode, seed)
-        if mode in ("no_coop", "force_coop"):        # fan-in rows (the cooperative tasks' subject), with all level digests
-            for seed, kw in [(5, dict(max_width=30, n_levels=120, R=18, p_w1=0.3, p_colour=0.5)), (6, dict(max_width=60, n_levels=40, R=32, p_w1=0.6)),
-                             (7, dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8))]:
-                _dp_both(gpu_ctx, graphgen.random_levelized(7100 + seed, **kw))
+        # fan-in rows (the cooperative tasks' and the row matrices' subject), with all level digests
+        for seed, kw in [(5, dict(max_width=30, n_levels=120, R=18, p_w1=0.3, p_colour=0.5)), (6, dict(max_width=60, n_levels=40, R=32, p_w1=0.6)),
+                         (7, dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8)), (8, dict(max_width=70, n_levels=12, R=4, extra_edges=3.0))]:
+            _dp_both(gpu_ctx, graphgen.random_levelized(7100 + seed, **kw))
     finally:
-        for k, v in {"fast": 1, "team": 0, "team_min_levels": 16, "team_max_tasks": 100, "adaptive_rc": 3, "coop": 1}.items():
+        for k, v in {"fast": 1, "adaptive_rc": 1, "coop": 1, "rowx": 1}.items():
             gpu_ctx.dp_set_option(k, v)
+
+
+def test_dp_large_recombination_budget(gpu_ctx):
+    """R >= 1024 (the level-0 initialisation used to be one over-sized block): values, edge lists and digests"""
+    _dp_both(gpu_ctx, graphgen.random_levelized(7300, max_width=5, n_levels=12, R=1100, p_w1=0.5))
+    _dp_both(gpu_ctx, graphgen.random_levelized(7301, max_width=3, n_levels=8, R=4096, p_w1=0.9))
 
 
 @pytest.mark.parametrize("seg_cells", [1, 5000, 200000])

@@ -76,3 +76,21 @@ def test_prefix_panel_is_a_panel(built_cpu, tmp_path):
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     summ = json.load(open(js))
     assert summ["len1"] > 0 and summ["len2"] > 0 and open(out).read().startswith(">sol_1 bp:")
+
+
+def test_unwritable_output_is_an_error(built_cpu, tmp_path):
+    """an -o path that cannot be opened must fail the run (exit code != 0), not report success without a FASTA"""
+    c = CASES["toy2_p2"]
+    cmd = [built_cpu, "-q", "-t2"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]),
+                                                  "-o", str(tmp_path / "no_such_dir" / "o.fa")]
+    p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"cannot open output file" in p.stderr
+
+
+def test_thread_count_zero_is_clamped(built_cpu, tmp_path):
+    """-t0 used to reach the OpenMP num_threads clauses unclamped"""
+    c = CASES["toy2_p2"]
+    out = tmp_path / "o.fa"
+    cmd = [built_cpu, "-q", "-t0"] + [a for a in c["args"] if not a.startswith("-t")] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["fasta_md5"]

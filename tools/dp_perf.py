@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Perf probe: load .dpg graphs, run the HIP DP in its modes, print timings.
-usage: python tools/dp_perf.py [--check] [--modes=team,fast,generic] graph.dpg ... """
+usage: python tools/dp_perf.py [--check] [--modes=fast,norowx,generic] graph.dpg ... """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,19 +8,20 @@ import numpy as np
 from dipgenie_amd import capi
 
 check = "--check" in sys.argv
-modes = "team,fast"
+modes = "fast"
 for a in sys.argv[1:]:
     if a.startswith("--modes="): modes = a.split("=")[1]
 paths = [a for a in sys.argv[1:] if not a.startswith("--")]
 ctx = capi.Context(0)
-OPT = {"team": (1, 1), "fast": (0, 1), "generic": (0, 0)}
+OPT = {"fast": (1, 1), "norowx": (0, 1), "generic": (1, 0)}     # (rowx, fast)
 for p in paths:
     g = capi.DpGraphArrays.load(p)
     t0 = time.time(); ctx.dp_load_graph(g); t1 = time.time()
     print(f"== {os.path.basename(p)}: L={g.n_levels} V={g.n_vertices} load {t1-t0:.2f}s", flush=True)
     ref = None
     for mode in modes.split(","):
-        ctx.dp_set_option("team", OPT[mode][0]); ctx.dp_set_option("fast", OPT[mode][1])
+        ctx.dp_set_option("rowx", OPT[mode][0]); ctx.dp_set_option("fast", OPT[mode][1])
+        ctx.dp_load_graph(g)                               # rowx takes effect at load
         for it in range(3):
             t0 = time.time(); out = ctx.dp_run(); dt = time.time() - t0
             tm = ctx.dp_timing()
