@@ -91,6 +91,9 @@ struct FastArgs {                                       // fast sweep kernel
     unsigned long long *digest;
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
     uint32_t buf_bytes;                                 // size of one padded state buffer
+#ifdef DG_SWEEP_PROBE
+    unsigned long long *probe;                          // measurement build: 8 words per level
+#endif
 };
 
 struct DpState {
@@ -135,6 +138,9 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
     DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain;
+#ifdef DG_SWEEP_PROBE
+    DevBuf d_probe;
+#endif
     std::vector<uint64_t> digest_host;
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -200,6 +200,13 @@ struct Run {
         if (n_win() == 1 && S.n_delta_blocks > 0) load_window(0);      // everything fits: computed once, up front (delta_ms)
         DG_HIP(hipEventRecord(S.ev[1], s));
         if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
+#ifdef DG_SWEEP_PROBE
+        {   // slot 0 of every level takes an atomicMin: start from all ones
+            std::vector<unsigned long long> init((size_t)S.L * 8, 0ULL);
+            for (int l = 0; l < S.L; ++l) init[(size_t)l * 8] = ~0ULL;
+            DG_HIP(hipMemcpy(S.d_probe.p, init.data(), 8 * init.size(), hipMemcpyHostToDevice));
+        }
+#endif
         sweep_init_state(S, s);
         if (n_seg == 1) {
             // whole lattice resident: one sweep with back-pointers, then the chain walk chunk by chunk, last first
@@ -254,6 +261,13 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         DG_HIP(hipMemcpyAsync(S.digest_host.data(), S.d_digest.p, 8 * (size_t)S.L, hipMemcpyDeviceToHost, s));
     }
     DG_HIP(hipStreamSynchronize(s));
+#ifdef DG_SWEEP_PROBE
+    if (const char *po = getenv("DG_PROBE_OUT")) {
+        std::vector<unsigned long long> pr((size_t)S.L * 8);
+        DG_HIP(hipMemcpy(pr.data(), S.d_probe.p, 8 * pr.size(), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(po, "wb")) { fwrite(pr.data(), 8, pr.size(), f); fclose(f); }
+    }
+#endif
     if (getenv("DG_DEBUG"))
         fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)run.n_launch, 1e3 * run.host_enqueue_s,
                 1e6 * run.host_enqueue_s / (double)std::max<int64_t>(run.n_launch, 1));

@@ -218,11 +218,28 @@ __device__ __forceinline__ void merge_best(int ov, uint32_t oo, bool same, int &
     bo = take ? oo : bo;
 }
 
+// Measurement build only (-DDG_SWEEP_PROBE, tools/probe build; never in the product library): one wave per destination row
+// stamps the 100 MHz real-time counter at the task's phase boundaries.
+#ifdef DG_SWEEP_PROBE
+#define DG_PROBE_BEGIN unsigned long long pq[6] = {0, 0, 0, 0, 0, 0}; \
+    const bool probe_on = A.probe != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0 && (int)blockIdx.z < d.k2;
+#define DG_PROBE(q) do { if (probe_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pq[q] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define DG_PROBE_END do { if (probe_on && (threadIdx.x & 63) == 0) { \
+        atomicMin(&A.probe[(size_t)lvl * 8 + 0], pq[0]); atomicMax(&A.probe[(size_t)lvl * 8 + 1], pq[5]); \
+        if ((int)blockIdx.z == d.k2 / 2) for (int q = 0; q < 6; ++q) A.probe[(size_t)lvl * 8 + 2 + q] = pq[q]; } } while (0)
+#else
+#define DG_PROBE_BEGIN
+#define DG_PROBE(q) do { } while (0)
+#define DG_PROBE_END do { } while (0)
+#endif
+
 template <int RC, bool DIGEST, bool GENERAL, int COOP>
 __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
                                            int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr) {
     const int lane = threadIdx.x & 63;
     const int RP = A.RP;
+    DG_PROBE_BEGIN
+    DG_PROBE(0);
     // first load round: every address below comes from kernel arguments and the block index alone
     const uint4 rr = A.rowrec[d.b0 + i2];                               // {eu0, du, pu0, pu1}
     uint2 sl = A.slots[d.slot_first + (int64_t)g * 64 + lane];
@@ -247,6 +264,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const int dT = has_delta ? d.T : 0;
     const int du = (int)rr.y;
     if (COOP == 1 && du > COOP_MIN) return;
+    DG_PROBE(1);
     const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;   // this wave's share of the row's in-edges
     int bval[RC];
     uint32_t bord[RC];
@@ -324,6 +342,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
             }
         }
     }
+    DG_PROBE(2);
     if (COOP == 2) {                                                    // partial bests of waves 1..3 -> wave 0
         if (part > 0) {
 #pragma unroll
@@ -356,6 +375,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     const int pj2 = lane_up1(j2);
     const bool head = act & ((lane == 0) | (pj2 != j2));
     unsigned long long dsum = 0;
+    DG_PROBE(3);
     if (head) {
 #pragma unroll
         for (int q = 0; q < RC; ++q) {
@@ -385,6 +405,11 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         }
     }
     if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+#ifdef DG_SWEEP_PROBE
+    if (probe_on) pq[4] = __builtin_amdgcn_s_memrealtime();
+    DG_PROBE(5);
+    DG_PROBE_END;
+#endif
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padded_base, uint32_t bytes) {
@@ -398,10 +423,13 @@ __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDes
     const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
-    if (COOP && (int)blockIdx.z >= d.k2) {
-        // cooperative region (blockDim = 4 waves): workgroup (x, y, k2 + 4 h + b) = slot block 4 x + b of the h-th heavy row
+    const int zc = COOP ? 4 * d.n_heavy : 0;                            // cooperative region: z < 4 n_heavy
+    if (COOP && (int)blockIdx.z < zc) {
+        // cooperative region (blockDim = 4 waves): workgroup z = 4 h + b = slot block 4 x + b of the h-th heavy row.  It is
+        // dispatched FIRST: its tasks (load round + LDS merge) are the longest of the launch, and started last they were
+        // the launch's tail (-3.6 % on the MHC-24 sweep against the region at z >= k2)
         __shared__ uint2 ex[3 * RC * 64];
-        const int hz = (int)blockIdx.z - d.k2;
+        const int hz = (int)blockIdx.z;
         const int g = (int)blockIdx.x * 4 + (hz & 3);
         if (g >= d.nblocks) return;                                     // workgroup-uniform: nobody is left at the barrier
         const int h = hz >> 2;
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDes
     }
     const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
-    const int i2 = (int)blockIdx.z;
+    const int i2 = (int)blockIdx.z - zc;
     sweep_task<RC, DIGEST, GENERAL, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
 }
 
@@ -450,6 +478,9 @@ void sweep_prepare(const DpState &S, SweepLaunch &X) {
     F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.rowx = S.d_rowx.as<uint32_t>(); F.dead_cols = A.dead_cols;
     F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
     F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
+#ifdef DG_SWEEP_PROBE
+    F.probe = S.d_probe.as<unsigned long long>();
+#endif
     F.pad_bytes = (int)(4 * S.pad_front);
     F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
 }

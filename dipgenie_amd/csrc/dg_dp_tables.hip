@@ -554,6 +554,9 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     DG_HIP(hipMemsetAsync(S.d_val[0].p, 0, S.d_val[0].bytes, s));
     DG_HIP(hipMemsetAsync(S.d_val[1].p, 0, S.d_val[1].bytes, s));
     if (int rc = S.d_digest.ensure(8 * (size_t)L)) return rc;
+#ifdef DG_SWEEP_PROBE
+    if (int rc = S.d_probe.ensure(64 * (size_t)L)) return rc;
+#endif
     if (int rc = S.d_trace.ensure(sizeof(TraceOut))) return rc;
     S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
     S.cap = 2 * (R + 8);                               // edge records of both paths

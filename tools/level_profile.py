@@ -50,3 +50,7 @@ table("largest in-degree of the level", [dcls(maxin[l]) for l in range(1, L)])
 def wcls(x): return "<32" if x < 32 else "<64" if x < 64 else "<128" if x < 128 else "<256" if x < 256 else ">=256"
 table("level width k2", [wcls(k[l]) for l in range(1, L)])
 table("in-degree class x variant", [dcls(maxin[l]) + " " + name[l - 1] for l in range(1, L)])
+if len(sys.argv) > 4:                                   # per-level arrays for offline analysis
+    variants = sorted(set(name))
+    np.savez_compressed(sys.argv[4], dur_us=dur.astype(np.float32), gap_us=gap.astype(np.float32), variant=np.array([variants.index(n) for n in name], np.int16),
+                        variants=np.array(variants), k=k.astype(np.int32), T=T.astype(np.int32), maxin=maxin.astype(np.int32))
