@@ -4,14 +4,21 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic MHC-24 --
-24 walks over the MHC_4 segment set (5 real + 19 seeded mosaics with private variants), diploid -p2
--R18, 4x synthetic 150-bp reads.  A *step* is one pass of the hot path over that input, with every
-input already resident in HBM: (a) minimizer scoring of the read set, sharded over the ranks by read
-(local HIP sketch -> RCCL all-reduce of the per-dictionary-minimizer hit vector + all-gather/merge of the
-spectrum), then (b) the pair-of-paths DP (delta precompute, level sweep, traceback) on the rank's GPU.
-The DP does not shard (replicas only), so with N ranks every rank solves one instance and
-`value` = (N x cells) / max-over-ranks time  ("scaling": "weak").
+N = 1 (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic MHC-24 -- 24 walks over the MHC_4
+segment set (5 real + 19 seeded mosaics with private variants), diploid -p2 -R18, 4x synthetic 150-bp reads.  A *step* is
+one pass of the hot path over that input, every input already resident in HBM: (a) minimizer scoring of the read set
+(HIP sketch, dictionary join, ids, histogram), then (b) the pair-of-paths DP (delta precompute, level sweep, traceback).
+`value` = DP state cells / s.  The same line carries `sketch_config4`: the 30x read set (configs[3]) scored on this one
+rank -- the N = 1 point of the scaling curve below.
+
+N > 1 (BASELINE.json configs[3]): what shards is the minimizer scoring -- north_star: "throughput ... reported at 1 GPU
+(DP) and 1/2/4/8 GPUs (minimizer scoring)"; the DP is a chain of 1.4 x 10^5 dependent levels and does not shard
+(replicas only).  A *step* is one scoring pass over the 1,007,415 x 150-bp 30x read set, sharded by read
+over the ranks (dipgenie_amd/dist_sketch.py: local HIP sketch, RCCL all-reduce of the dictionary hit vector, hash-range
+all-to-all of (hash, count) runs, sharded merge, one fused all-reduce of range sizes / histogram / ids).  `metric` =
+sketch_reads_per_s, `value` = reads x steps / max-over-ranks time, "scaling": "strong" (the read set is fixed); rank 0
+re-scores the whole set alone afterwards and every replicated output must be identical.  One DP instance per rank is
+timed beside it as `dp_replicated` (informational).
 """
 import argparse
 import json
@@ -134,18 +141,11 @@ def reference_baseline(cache, workload, bench_gfa, device):
                       f"{cells} cells): its DP function took {dp_s:.2f} s of {wall:.1f} s end to end; FASTA md5 matches the golden"}
 
 
-def sketch_config4(cache, ctx, sk, dict_t, device, world, rank, backend, K, W, reps=5):
-    """BASELINE configs[3]: 30x reads (10^6 x 150 bp) on the same 24-walk panel, minimizer scoring sharded over the ranks
-    by read -- local HIP sketch, RCCL all-reduce of the dictionary hit vector, all-gather + device merge of the spectrum.
-    Untimed cross-check at N > 1: rank 0 sketches the whole set alone and must get the same spectrum and hit vector."""
+def load_config4_shard(cache, device, world, rank):
+    """BASELINE configs[3]: 30x reads (1,007,415 x 150 bp, seed 30) on the bench panel; this rank's contiguous block, resident"""
     import torch
-    import torch.distributed as dist
     from dipgenie_amd import synth
     from dipgenie_amd.dist_sketch import shard_bounds
-    if rank == 0:
-        path = synth.ensure_mhc24_reads(os.path.join(cache, "mhc24"))
-    if world > 1:
-        dist.barrier()
     path = synth.ensure_mhc24_reads(os.path.join(cache, "mhc24"))
     arr = np.load(path, mmap_mode="r")
     n, rl = arr.shape
@@ -155,54 +155,34 @@ def sketch_config4(cache, ctx, sk, dict_t, device, world, rank, backend, K, W, r
         o = (torch.arange(hi - lo + 1, dtype=torch.int64) * rl).to(device)
         return b, o
     lo, hi = shard_bounds(n, world, rank)
-    bases_t, off_t = resident(lo, hi)
+    return resident(lo, hi), resident, int(n), int(rl)
 
-    def one():
-        h, c = sk.local(bases_t, off_t, K, W)
-        counts = sk.dictionary_counts(dict_t, h, c)
-        gh, gc = sk.global_spectrum(h, c)
-        torch.cuda.synchronize()
-        return counts, gh, gc
-    counts, gh, gc = one()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    dev_ms = 0.0
-    for _ in range(reps):
-        counts, gh, gc = one()
-        tm = ctx.sketch_timing()
-        dev_ms += tm.total_ms
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el, dev_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el, dev_ms = (float(x) for x in t.tolist())
-    if rank != 0:
-        return None
-    res = {"workload": f"{n} x {rl}-bp reads (30x, seed 30) on the bench panel, sharded by read over {world} rank(s)",
-           "reads": int(n), "passes": reps, "reads_per_s": n * reps / el, "Gbp_per_s": n * rl * reps / el / 1e9, "ms_per_pass": 1e3 * el / reps,
-           "local_sketch_ms_max_rank": dev_ms / reps, "distinct_hashes": int(gh.numel()), "dictionary_hits": int((counts > 0).sum().item()),
-           "collectives": "none (1 rank)" if world == 1 else f"{backend}: all-reduce int32[{int(dict_t.numel())}] + all-gather of (hash, count) runs"}
-    if world > 1:
-        fb, fo = resident(0, n)
-        h1, c1 = sk.local(fb, fo, K, W)
-        torch.cuda.synchronize()
-        same = bool(h1.numel() == gh.numel() and torch.equal(h1, gh) and torch.equal(c1, gc))
-        cnt1 = torch.zeros_like(counts)
-        from dipgenie_amd import capi
-        torch.cuda.synchronize()
-        capi._check(capi.lib.dg_sketch_count_dictionary_dev(ctx.h, dict_t.data_ptr(), dict_t.numel(), h1.data_ptr(), c1.data_ptr(), h1.numel(),
-                                                            cnt1.data_ptr()), "dg_sketch_count_dictionary_dev")
-        sk.ctx_sync()
-        same = same and torch.equal(cnt1, counts)
-        res["matches_single_rank"] = same
-        if not same:
-            raise SystemExit("sharded config-4 sketch differs from the single-rank sketch")
-    return res
+
+def same_score(a, b):
+    import torch
+    return bool(a.n_distinct == b.n_distinct and torch.equal(a.counts, b.counts) and torch.equal(a.ids, b.ids) and torch.equal(a.hist, b.hist))
+
+
+def attach_profile(roof, launch_profile, workload):
+    """HBM traffic (PMC) and the rocprofv3 kernel-trace average of the same kernels on the same workload come from the
+    committed profile summary (rocprofv3 cannot run inside this process).  It is used only if it was taken on exactly
+    the launches of THIS run: same kernel variants, same launch count per variant; otherwise the fields stay null."""
+    path = os.path.join(ROOT, "profiles", "r02_roofline.json")
+    roof["launch_profile"] = launch_profile
+    if workload != "mhc24" or not os.path.exists(path):
+        return
+    with open(path) as f:
+        prof = json.load(f)
+    if prof.get("launch_profile") != launch_profile:
+        roof["traffic_note"] = "profiles/r02_roofline.json was taken on a different set of sweep launches: stale, ignored (re-run tools/roofline_profile.sh)"
+        return
+    roof["traffic"] = prof["hbm_bytes_per_launch"]["high"]
+    roof["traffic_unit"] = "bytes/launch"
+    roof["traffic_range"] = [prof["hbm_bytes_per_launch"]["low"], prof["hbm_bytes_per_launch"]["high"]]
+    roof["traffic_source"] = ("profiles/r02_roofline.json (committed, not measured in this run; launch profile identical to this run's): WRITE_SIZE + "
+                              "calibrated FETCH_SIZE of all sweep launches of one DP pass, separate --pmc passes, plain launches (sync_every)")
+    roof["avg_launch_ms_rocprof"] = prof["kernel_trace"]["avg_launch_ns"] / 1e6
+    roof["frac_rocprof"] = roof["algorithmic_bytes_per_launch"] / prof["kernel_trace"]["avg_launch_ns"] / roof["peak"]
 
 
 def main():
@@ -216,7 +196,7 @@ def main():
     ap.add_argument("--cpu-sample-cells", type=float, default=6e8)
     ap.add_argument("--no-concurrent", action="store_true", help="skip the multi-instance-per-GPU measurement")
     ap.add_argument("--no-reference-baseline", action="store_true", help="skip the oracle/_ref run (about 30 s)")
-    ap.add_argument("--no-config4", action="store_true", help="skip the 30x read-set sketch measurement (BASELINE configs[3])")
+    ap.add_argument("--no-config4", action="store_true", help="N = 1 only: skip the 30x read-set scoring measurement (BASELINE configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -242,22 +222,31 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(*vals):
+        if world == 1:
+            return vals
+        t = torch.tensor(list(vals), dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return tuple(float(x) for x in t.tolist())
+
     # ---------------------------------------------------------------- build + inputs (untimed)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build(verbose=False)
-    if world > 1:
-        dist.barrier()
+    barrier()
     from dipgenie_amd import capi, synth
-    from dipgenie_amd.dist_sketch import ShardedSketch, shard_bounds
+    from dipgenie_amd.dist_sketch import HipOps, ShardedSketch, shard_bounds
 
     os.makedirs(args.cache, exist_ok=True)
     if args.workload == "mhc24":
         name = "synthetic MHC-24 (5 real + 19 mosaic walks, seed 24), -p2 -R18, 4x 150-bp reads (seed 4)"
         if rank == 0:
             gfa, reads_path, info = synth.ensure_mhc24(os.path.join(args.cache, "mhc24"))
-        if world > 1:
-            dist.barrier()
+        barrier()
         gfa, reads_path, info = synth.ensure_mhc24(os.path.join(args.cache, "mhc24"))
     else:
         name = "MHC_4 (5 walks) + CHM13 0.5x reads, -p2 -R18"
@@ -277,12 +266,13 @@ def main():
         e2e["wall_s"] = time.time() - t0                    # the timed run writes nothing but the FASTA (+ the summary)
         subprocess.run(base_cmd + ["-D", pre], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)   # same run again, dumping the .dpg
         log(f"end-to-end CLI run: {e2e['wall_s']:.2f} s, DP value {e2e['dp_value']}")
-    if world > 1:
-        dist.barrier()
+    barrier()
     g = capi.DpGraphArrays.load(pre + ".dpg")
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(local_rank)                         # DP instance of this rank
     ctx.dp_load_graph(g)                                   # graph resident in HBM from here on
+    ctx_sk = capi.Context(local_rank)                      # scoring: its own context, on a torch stream shared with the collectives
+    sk = ShardedSketch(HipOps(ctx_sk, device), device)
 
     # reads: this rank's contiguous shard, resident on the GPU; haplotype-minimizer dictionary D
     if reads_path.endswith(".gz"):
@@ -305,89 +295,129 @@ def main():
         dict_parts.append(h)
     D = np.unique(np.concatenate(dict_parts))
     dict_t = torch.from_numpy(D.view(np.int64).copy()).to(device)
-    sk = ShardedSketch(ctx, device)
     del seqs, walks, dict_parts
+    cfg4 = None
+    if args.workload == "mhc24" and (world > 1 or not args.no_config4):
+        if rank == 0:
+            synth.ensure_mhc24_reads(os.path.join(args.cache, "mhc24"))
+        barrier()
+        cfg4 = load_config4_shard(args.cache, device, world, rank)
 
-    def step():
-        t0 = time.perf_counter()
-        h, c = sk.local(bases_t, off_t, K, W)
-        counts = sk.dictionary_counts(dict_t, h, c)         # RCCL all-reduce(sum) of the hit vector
-        gh, gc = sk.global_spectrum(h, c)                   # all-gather + device merge
+    def timed(step, n_warm, n_steps):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks"""
+        for _ in range(n_warm):
+            step()
+        barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        out = ctx.dp_run()                                  # synchronises
-        t2 = time.perf_counter()
-        return out, counts, gh, (t1 - t0), (t2 - t1)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)[0]
 
-    for _ in range(args.warmup):
-        out, counts, gh, _, _ = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_begin = time.perf_counter()
-    sk_s = dp_s = 0.0
-    fwd_ms = dl_ms = tb_ms = 0.0
-    for _ in range(args.steps):
-        out, counts, gh, a, b = step()
-        sk_s += a
-        dp_s += b
-        tm = ctx.dp_timing()
-        fwd_ms += tm.forward_ms; dl_ms += tm.delta_ms; tb_ms += tm.traceback_ms
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_begin
-    if world > 1:
-        t = torch.tensor([elapsed, sk_s, dp_s], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, sk_s, dp_s = (float(x) for x in t.tolist())
+    last = {}
+    if world == 1:
+        # ------------------------------------------------------------ N = 1: the DP headline (BASELINE configs[2])
+        acc = {"sk": 0.0, "dp": 0.0, "fwd": 0.0, "dl": 0.0, "tb": 0.0, "on": False}
 
-    sk4 = None
-    if args.workload == "mhc24" and not args.no_config4:
-        sk4 = sketch_config4(args.cache, ctx, sk, dict_t, device, world, rank, backend, K, W)
+        def step():
+            t0 = time.perf_counter()
+            last["score"] = sk.score(bases_t, off_t, dict_t, K, W)      # minimizer scoring of the 4x read set
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            last["out"] = ctx.dp_run()                                   # delta + sweep + traceback; synchronises
+            t2 = time.perf_counter()
+            if acc["on"]:
+                tm = ctx.dp_timing()
+                acc["sk"] += t1 - t0; acc["dp"] += t2 - t1
+                acc["fwd"] += tm.forward_ms; acc["dl"] += tm.delta_ms; acc["tb"] += tm.traceback_ms
+        for _ in range(args.warmup):
+            step()
+        acc["on"] = True
+        elapsed = timed(step, 0, args.steps)
+        out, score = last["out"], last["score"]
+        sk4 = None
+        if cfg4 is not None:                                             # BASELINE configs[3] at one rank: the N = 1 point of the scaling curve
+            (b4, o4), _resident, n4, rl4 = cfg4
+            el4 = timed(lambda: last.__setitem__("s4", sk.score(b4, o4, dict_t, K, W)), 1, 5)
+            s4 = last["s4"]
+            sk4 = {"workload": f"{n4} x {rl4}-bp reads (30x, seed 30) on the bench panel, 1 rank", "reads": n4, "passes": 5,
+                   "reads_per_s": n4 * 5 / el4, "Gbp_per_s": n4 * rl4 * 5 / el4 / 1e9, "ms_per_pass": 1e3 * el4 / 5,
+                   "local_sketch_ms": ctx_sk.sketch_timing().total_ms, "distinct_hashes": s4.n_distinct,
+                   "dictionary_hits": int((s4.counts > 0).sum().item()), "collectives": "none (1 rank)"}
+    else:
+        # ------------------------------------------------------------ N > 1: read-sharded scoring (BASELINE configs[3])
+        if cfg4 is None:
+            raise SystemExit("--gpus N > 1 measures the sharded scoring of the mhc24 30x read set")
+        (b4, o4), resident, n4, rl4 = cfg4
+
+        def step():
+            last["s4"] = sk.score(b4, o4, dict_t, K, W)
+        elapsed = timed(step, args.warmup, args.steps)
+        s4 = last["s4"]
+        local_ms = max_over_ranks(ctx_sk.sketch_timing().total_ms)[0]
+        # untimed cross-check: rank 0 scores the whole read set alone; every replicated output must be identical
+        ok = 1.0
+        if rank == 0:
+            solo = ShardedSketch(sk.ops, device)
+            solo.world, solo.rank = 1, 0
+            fb, fo = resident(0, n4)
+            ok = 1.0 if same_score(solo.score(fb, fo, dict_t, K, W), s4) else 0.0
+            del fb, fo
+        if max_over_ranks(1.0 - ok)[0] > 0:
+            raise SystemExit("sharded config-4 scoring differs from the single-rank scoring")
+        # informational: one DP instance per rank (the DP does not shard, SURVEY.md s8e), 2 passes each
+        dp_el = timed(lambda: last.__setitem__("out", ctx.dp_run()), 1, 2)
+        out = last["out"]
 
     if rank == 0:
         if e2e is not None and out.value != e2e["dp_value"]:
             raise SystemExit(f"bench DP value {out.value} != CLI DP value {e2e['dp_value']}")
-        if e2e is not None and int(gh.numel()) != int(e2e["spectrum"]):     # sharded sketch == single-process sketch of the CLI
-            raise SystemExit(f"sharded spectrum size {gh.numel()} != CLI spectrum size {e2e['spectrum']}")
         steps = args.steps
         cells = int(out.cells)
         tm = ctx.dp_timing()
-        # algorithmic bytes of one DP pass, SURVEY.md s8d: 32 B/cell + 16 B/edge-pair + 4 B/colour entry read
-        alg_bytes = 32.0 * cells + 16.0 * tm.edge_pairs + 4.0 * tm.colour_entries
-        fwd_s = fwd_ms / 1e3 / steps
-        n_launch = max(int(tm.n_forward_launches), 1)
-        achieved = alg_bytes / fwd_s / 1e9
-        line = {
-            "metric": "dp_state_cells_per_s", "value": world * cells * steps / elapsed, "unit": "cells/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": name, "R": R, "k": K, "w": W, "levels": g.n_levels, "vertices": g.n_vertices,
-                       "cells_per_pass": cells, "relaxations_per_pass": int(out.relaxations), "reads": len(all_reads),
-                       "parallelism": f"sketch sharded over {world} rank(s) by read (RCCL all-reduce + all-gather); DP replica per rank"},
-            "dp_ms": {"delta": dl_ms / steps, "forward": fwd_ms / steps, "traceback": tb_ms / steps, "wall": 1e3 * dp_s / steps},
-            "reads_per_s": len(all_reads) * steps / sk_s if sk_s > 0 else None,
-            "sketch_ms_per_step": 1e3 * sk_s / steps,
-            "roofline": {"bound": "hbm", "kernel": "dp_level sweep (forward)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes / n_launch, "launches": n_launch, "avg_launch_ms": 1e3 * fwd_s / n_launch,
-                         "dependency_chain_levels": g.n_levels},
-        }
-        # HBM traffic of the same kernels on the same workload, from the committed PMC passes (rocprofv3 cannot run
-        # inside this process): bytes per launch, upper end of the calibrated range
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_mhc24_traffic.json")
-        if args.workload == "mhc24" and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            if pmc.get("launches") == n_launch:
-                line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]["high"]
-                line["roofline"]["traffic_unit"] = "bytes/launch"
-                line["roofline"]["traffic_range"] = [pmc["hbm_bytes_per_launch"]["low"], pmc["hbm_bytes_per_launch"]["high"]]
-                line["roofline"]["traffic_source"] = ("profiles/r01_pmc_mhc24_traffic.json: WRITE_SIZE + calibrated FETCH_SIZE of all "
-                                                      f"{n_launch} sweep launches of one DP pass on this workload (separate --pmc passes)")
-        if sk4 is not None:
-            line["sketch_config4"] = sk4
+        config = {"workload": name, "R": R, "k": K, "w": W, "levels": g.n_levels, "vertices": g.n_vertices,
+                  "cells_per_pass": cells, "relaxations_per_pass": int(out.relaxations), "reads": len(all_reads)}
+        if world == 1:
+            if e2e is not None and score.n_distinct != int(e2e["spectrum"]):     # scoring class == single-process sketch of the CLI
+                raise SystemExit(f"spectrum size {score.n_distinct} != CLI spectrum size {e2e['spectrum']}")
+            # algorithmic bytes of one DP pass, SURVEY.md s8d: 32 B/cell + 16 B/edge-pair + 4 B/colour entry read
+            alg_bytes = 32.0 * cells + 16.0 * tm.edge_pairs + 4.0 * tm.colour_entries
+            fwd_s = acc["fwd"] / 1e3 / steps
+            n_launch = max(int(tm.n_forward_launches), 1)
+            achieved = alg_bytes / fwd_s / 1e9
+            config["parallelism"] = "1 GPU: minimizer scoring + DP on the same device"
+            line = {
+                "metric": "dp_state_cells_per_s", "value": cells * steps / elapsed, "unit": "cells/s",
+                "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": config,
+                "dp_ms": {"delta": acc["dl"] / steps, "forward": acc["fwd"] / steps, "traceback": acc["tb"] / steps, "wall": 1e3 * acc["dp"] / steps},
+                "reads_per_s": len(all_reads) * steps / acc["sk"] if acc["sk"] > 0 else None,
+                "sketch_ms_per_step": 1e3 * acc["sk"] / steps,
+                "roofline": {"bound": "hbm", "kernel": "dp_sweep_fast_kernel (level sweep, forward)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                             "algorithmic_bytes_per_launch": alg_bytes / n_launch, "launches": n_launch, "avg_launch_ms": 1e3 * fwd_s / n_launch,
+                             "dependency_chain_levels": g.n_levels},
+            }
+            attach_profile(line["roofline"], ctx.dp_launch_profile(), args.workload)
+            if sk4 is not None:
+                line["sketch_config4"] = sk4
+        else:
+            config = {"workload": f"{n4} x {rl4}-bp reads (30x, seed 30) on the synthetic MHC-24 panel (BASELINE configs[3]), k={K} w={W}, "
+                                  f"dictionary of {int(dict_t.numel())} haplotype minimizers", "reads": n4, "read_length": rl4,
+                      "parallelism": f"reads sharded over {world} ranks; {backend}: async all-reduce int32[{int(dict_t.numel())}] (hit vector) + all-gather of the "
+                                     f"{world}x{world} send counts + all-to-all of (hash, count) runs by hash range + one fused all-reduce (range sizes, histogram, ids)"}
+            line = {
+                "metric": "sketch_reads_per_s", "value": n4 * steps / elapsed, "unit": "reads/s",
+                "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": config,
+                "Gbp_per_s": n4 * rl4 * steps / elapsed / 1e9, "local_sketch_ms_max_rank": local_ms, "distinct_hashes": s4.n_distinct,
+                "range_sizes": s4.range_sizes, "dictionary_hits": int((s4.counts > 0).sum().item()), "matches_single_rank": True,
+                "n1_reference": "the N = 1 run reports the same measurement as sketch_config4.reads_per_s",
+                "dp_replicated": {"value": world * cells * 2 / dp_el, "unit": "cells/s", "passes_each": 2,
+                                  "note": "one independent DP instance per rank (the DP does not shard); informational, not `value`"},
+            }
         if e2e is not None:
             line["end_to_end_s"] = e2e["wall_s"]
             line["end_to_end_stages_s"] = e2e.get("stages")
@@ -419,7 +449,7 @@ def main():
                 if any(r.key() != out.key() for r in res):
                     raise SystemExit("concurrent instances disagree with the single-instance result")
                 line["concurrent_instances"] = {"instances": n_inst, "passes_each": 3, "value": n_inst * 3 * cells / dt, "unit": "cells/s",
-                                                "vs_single_instance": (n_inst * 3 * cells / dt) / (cells * steps / dp_s),
+                                                "vs_single_instance": (n_inst * 3 * cells / dt) / (cells * steps / acc["dp"]),
                                                 "note": "independent samples on one GPU (one dg_ctx per sample); informational, not `value`"}
                 for c2 in extra:
                     c2.close()
@@ -442,6 +472,7 @@ def main():
                 line["cpu_baseline_port"] = port
         print(json.dumps(line), flush=True)
     ctx.close()
+    ctx_sk.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -48,8 +48,9 @@ class SketchTiming(C.Structure):
 SYMBOLS = [
     "dg_create", "dg_destroy", "dg_last_error", "dg_set_stream", "dg_synchronize", "dg_device_info",
     "dg_dp_prealloc", "dg_dp_load_graph", "dg_dp_run", "dg_dp_get_timing", "dg_dp_solve_diploid", "dg_dp_get_level_digest",
-    "dg_dp_set_option", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
+    "dg_dp_set_option", "dg_dp_get_launch_profile", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
+    "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -67,6 +68,7 @@ lib.dg_dp_get_timing.argtypes = [C.c_void_p, C.POINTER(DpTiming)]
 lib.dg_dp_solve_diploid.argtypes = [C.c_void_p, C.POINTER(DpGraph), C.POINTER(DpResult)]
 lib.dg_dp_get_level_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 lib.dg_dp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+lib.dg_dp_get_launch_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
 lib.dg_sketch_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
 lib.dg_sketch_haplotype.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_int,
@@ -80,6 +82,9 @@ lib.dg_sketch_reads_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 lib.dg_sketch_count_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
 lib.dg_sketch_merge_runs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.POINTER(C.c_int64)]
+lib.dg_sketch_partition_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+lib.dg_sketch_rank_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+lib.dg_sketch_histogram_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 
 
 class DgError(RuntimeError):
@@ -219,6 +224,12 @@ class Context:
         t = DpTiming()
         _check(lib.dg_dp_get_timing(self.h, C.byref(t)), "dg_dp_get_timing")
         return t
+
+    def dp_launch_profile(self):
+        """{kernel variant: launches} of the last dp_run"""
+        buf = C.create_string_buffer(8192)
+        _check(lib.dg_dp_get_launch_profile(self.h, buf, 8192), "dg_dp_get_launch_profile")
+        return {k: int(v) for k, v in (item.rsplit(":", 1) for item in buf.value.decode().split())}
 
     def dp_level_digest(self, n_levels):
         out = np.zeros(n_levels, np.uint64)

@@ -142,6 +142,8 @@ struct DpState {
     DevBuf d_probe;
 #endif
     std::vector<uint64_t> digest_host;
+    // launches of the last run per sweep kernel variant: index = rc * 4 + general * 2 + coop (rc 0 = generic kernel)
+    int64_t launch_hist[64 * 4] = {};
     dg_dp_timing timing;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // The resident back-pointer lattice lives in a pool of equal chunks that a background thread allocates one by

@@ -250,6 +250,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     DpState &S = *Sp;
     Run run(c, S);
     hipStream_t s = c->stream;
+    memset(S.launch_hist, 0, sizeof S.launch_hist);
     if (int rc = run.wait_for_chunks()) return rc;
     if (int rc = run.forward_and_trace()) return rc;
     TraceOut to;
@@ -332,6 +333,22 @@ extern "C" int dg_dp_get_level_digest(dg_ctx *c, uint64_t *out, int64_t n) {
     if (!c || !c->dp || !out) { dgi::set_error("dg_dp_get_level_digest: no state"); return DG_ERR_STATE; }
     if ((int64_t)c->dp->digest_host.size() != n) { dgi::set_error("digest not collected (set option digest=1) or size mismatch"); return DG_ERR_STATE; }
     memcpy(out, c->dp->digest_host.data(), 8 * (size_t)n);
+    return DG_OK;
+}
+extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
+    if (!c || !c->dp || !buf || cap < 2) { dgi::set_error("dg_dp_get_launch_profile: no state"); return DG_ERR_STATE; }
+    std::string out;
+    for (int q = 0; q < 64 * 4; ++q) {
+        const int64_t n = c->dp->launch_hist[q];
+        if (!n) continue;
+        char item[96];
+        if (q == 0) snprintf(item, sizeof item, "dp_sweep_kernel:%lld", (long long)n);
+        else snprintf(item, sizeof item, "dp_sweep_fast_kernel<%d,%s,%s>:%lld", q / 4, (q & 2) ? "general" : "lean", (q & 1) ? "coop" : "plain", (long long)n);
+        if (!out.empty()) out += ' ';
+        out += item;
+    }
+    if ((int)out.size() + 1 > cap) { dgi::set_error("dg_dp_get_launch_profile: buffer too small (%zu needed)", out.size() + 1); return DG_ERR_ARG; }
+    memcpy(buf, out.c_str(), out.size() + 1);
     return DG_OK;
 }
 // Options: parity / test knobs (digest, fast, adaptive_rc, coop, rowx, segment_cells, delta_cap_entries, lattice_chunk_cells,

@@ -531,6 +531,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
         const int32_t *hv = S.d_heavy.as<int32_t>();
         const FastArgs &F = X.F;
+        S.launch_hist[(rc & 63) * 4 + (d.fast_ok == 2 ? 2 : 0) + (coop ? 1 : 0)]++;
 #define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, F, d, l, hv); \
                               else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
 #define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
@@ -551,6 +552,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
         const unsigned grid = (unsigned)std::min<int64_t>((ntask + 3) / 4, S.max_blocks);
         const SweepArgs &A = X.A;
+        S.launch_hist[0]++;
 #define DG_SWEEP(RCV, DG) hipLaunchKernelGGL((dp_sweep_kernel<RCV, DG>), dim3(grid), dim3(256), 0, s, A, l)
         if (S.want_digest) { if (X.rc_sel == 8) DG_SWEEP(8, true); else if (X.rc_sel == 19) DG_SWEEP(19, true); else DG_SWEEP(33, true); }
         else { if (X.rc_sel == 8) DG_SWEEP(8, false); else if (X.rc_sel == 19) DG_SWEEP(19, false); else DG_SWEEP(33, false); }

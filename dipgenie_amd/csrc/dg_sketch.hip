@@ -278,6 +278,39 @@ __global__ void dict_count_kernel(const uint64_t *__restrict__ dict, int64_t n_d
     if (lo < n && hash[lo] == key) out[i] += cnt[lo];
 }
 
+// ---- read-sharded scoring (one rank per GPU): hash-range partition, global ranks, multiplicity histogram ----
+// owner of a hash when the uint64 space is cut into `world` equal ranges (hashes are MurmurHash3 outputs: uniform)
+__host__ __device__ __forceinline__ int hash_owner(uint64_t h, int world) { return (int)(((h >> 32) * (uint64_t)world) >> 32); }
+
+// split[r] = first index of the sorted hash list whose owner is >= r  (r = 0 .. world; split[world] = n)
+__global__ void partition_kernel(const uint64_t *__restrict__ hash, int64_t n, int world, int64_t *__restrict__ split) {
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r > world) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hash_owner(hash[mid], world) < r) lo = mid + 1; else hi = mid; }
+    split[r] = lo;
+}
+
+// rank1[i] += base + idx + 1 for every dictionary hash found in this rank's range of the merged spectrum (owner only:
+// a sum over ranks leaves global id + 1, 0 = not a read minimizer)
+__global__ void dict_rank_kernel(const uint64_t *__restrict__ dict, int64_t n_dict, const uint64_t *__restrict__ hash, int64_t n, int64_t base,
+                                 int64_t *__restrict__ rank1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dict) return;
+    const uint64_t key = dict[i];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hash[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < n && hash[lo] == key) rank1[i] += base + lo + 1;
+}
+
+// hist[min(count, n_bins - 1)] += 1 per spectrum entry (solver.cpp:745-755 Hist_kmer, sharded)
+__global__ void mult_hist_kernel(const int32_t *__restrict__ cnt, int64_t n, int n_bins, unsigned long long *__restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = min(max(cnt[i], 0), n_bins - 1);
+    atomicAdd(&hist[m], 1ULL);
+}
+
 // ------------------------------------------------------------------ host side
 static SketchState &state(dg_ctx *c) {
     if (!c->sk) c->sk = new SketchState();
@@ -544,5 +577,31 @@ extern "C" int dg_sketch_merge_runs_dev(dg_ctx *c, const uint64_t *hash_dev, con
     DG_HIP(hipMemcpyAsync(out_count_dev, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToDevice, s));
     DG_HIP(hipStreamSynchronize(s));
     *n_out = (int64_t)nd;
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_partition_dev(dg_ctx *c, const uint64_t *hash_dev, int64_t n, int world, int64_t *split_dev) {
+    if (int rc = bind(c)) return rc;
+    if (world < 1 || world > 4096 || !split_dev || n < 0) { set_error("dg_sketch_partition_dev: bad arguments"); return DG_ERR_ARG; }
+    hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((world + 1 + 63) / 64)), dim3(64), 0, c->stream, hash_dev, n, world, split_dev);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_rank_dictionary_dev(dg_ctx *c, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev, int64_t n, int64_t base,
+                                             int64_t *rank1_dev) {
+    if (int rc = bind(c)) return rc;
+    if (n_dict <= 0) return DG_OK;
+    hipLaunchKernelGGL(dict_rank_kernel, dim3((unsigned)((n_dict + 255) / 256)), dim3(256), 0, c->stream, dict_dev, n_dict, hash_dev, n, base, rank1_dev);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_histogram_dev(dg_ctx *c, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev) {
+    if (int rc = bind(c)) return rc;
+    if (n_bins < 2 || !hist_dev) { set_error("dg_sketch_histogram_dev: bad arguments"); return DG_ERR_ARG; }
+    if (n <= 0) return DG_OK;
+    hipLaunchKernelGGL(mult_hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, count_dev, n, n_bins, (unsigned long long *)hist_dev);
+    DG_HIP(hipGetLastError());
     return DG_OK;
 }

@@ -1,22 +1,32 @@
 """Read-sharded minimizer scoring across the GPUs of one node (one process per GPU, torch.distributed).
 
-north_star: "the per-read minimizer extraction + graph-hit counting shards naturally over reads across
-the 8 GPUs of one node with RCCL all-reduce of per-haplotype hit vectors over xGMI".  Each rank sketches
-its contiguous block of reads with the HIP kernels (C ABI, device-resident buffers), then
+north_star: "the per-read minimizer extraction + graph-hit counting shards naturally over reads across the 8 GPUs of one
+node with RCCL all-reduce of per-haplotype hit vectors over xGMI".  Semantics restated: Solver::compute_hashes over all
+reads, Sp_R / ids / kmer_count / Hist_kmer (/root/reference/src/solver.cpp:526-555, 711-755), sharded as SURVEY.md s8e:
 
-  1. dictionary path: every rank holds the sorted haplotype-minimizer dictionary D (M hashes); the local
-     (hash, #reads) list is joined against D into count[M] (int32) and ALL-REDUCED (sum) -- the only
-     collective the DP needs (anchor multiplicities);
-  2. spectrum path: the local sorted distinct (hash, count) runs are ALL-GATHERED (padded to the max
-     length) and merged (radix sort + reduce-by-key on device) so that every rank holds the exact global
-     Sp_R / kmer_count (needed for anchor ranks and the multiplicity histogram).
+  local     every rank sketches its contiguous block of reads on its GPU -> sorted distinct (hash, #reads) run;
+  (1) dictionary path   the run is joined against the sorted haplotype-minimizer dictionary D (M hashes, resident on
+      every rank) into count[M]; ALL-REDUCE(sum) -- issued asynchronously, it overlaps the exchange below;
+  (2) spectrum path     the uint64 hash space is cut into `world` equal ranges (MurmurHash3 outputs are uniform), rank r
+      owns range r: one ALL-GATHER of the world x world send-count matrix (the only size exchange, one host read), one
+      ALL-TO-ALL of (hash, count) runs, local merge (radix sort + reduce-by-key) -> the rank's range of the exact global
+      spectrum.  Nothing is replicated: the merge shrinks with the number of ranks;
+  (3) one fused ALL-REDUCE(sum) of [distinct count per range | multiplicity histogram | id + 1 of every dictionary hash
+      inside its owner's range]: every rank then knows count_sp_r, Hist_kmer and -- adding the exclusive scan of the
+      per-range counts, the owner being a function of the hash -- the global Sp_R id of every dictionary hit (the only
+      ids the DP stage consumes).
 
-torch is used for device memory, streams and the collectives only ("nccl" == RCCL on ROCm; "gloo" on
-CPU for the tests, where `local_sketch` is injected by the test).
+torch is plumbing here: device memory, one stream, the collectives ("nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+Every device operation goes through an `ops` object: `HipOps` (the C ABI of libdipgenie_hip.so on CUDA tensors -- the
+product; there is no CPU implementation in this package) or a shim injected by the tests.
 """
-import numpy as np
+import ctypes as C
+from dataclasses import dataclass
+
 import torch
 import torch.distributed as dist
+
+HIST_BINS = 4096            # multiplicities >= HIST_BINS - 1 share the last bin
 
 
 def shard_bounds(n_reads, world, rank):
@@ -26,100 +36,158 @@ def shard_bounds(n_reads, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _u64_as_i64(t):
-    return t.view(torch.int64)
+def hash_owner(hash_i64, world):
+    """owner range of uint64 hashes held as int64 tensors: floor(hi32 * world / 2^32) (dg_sketch.hip: hash_owner)"""
+    hi = (hash_i64 >> 32) & 0xFFFFFFFF
+    return (hi * world) >> 32
 
 
-def _coll_device(device):
-    """gloo (CPU tests / one-GPU rehearsals) moves data through host tensors; RCCL works on the device tensors"""
-    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+class HipOps:
+    """The device operations of the sharded path on CUDA tensors, through the C ABI.  The ctx adopts `stream` (a
+    torch.cuda.Stream): library kernels, torch kernels and the collectives are then ordered by that one stream, no host
+    synchronisation is needed for hand-offs (the entry points that return a size still wait for it)."""
 
-
-def allgather_runs(hash_t, count_t, device):
-    """all-gather variable-length (hash uint64-as-int64, count int32) runs; returns concatenated tensors."""
-    out_device = device
-    device = _coll_device(device)
-    hash_t, count_t = hash_t.to(device), count_t.to(device)
-    world = dist.get_world_size()
-    n = torch.tensor([hash_t.numel()], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(max(sizes), 1)
-    hp = torch.zeros(m, dtype=torch.int64, device=device)
-    cp = torch.zeros(m, dtype=torch.int32, device=device)
-    hp[: hash_t.numel()] = hash_t
-    cp[: count_t.numel()] = count_t
-    hs = [torch.empty_like(hp) for _ in range(world)]
-    cs = [torch.empty_like(cp) for _ in range(world)]
-    dist.all_gather(hs, hp)
-    dist.all_gather(cs, cp)
-    return torch.cat([h[:s] for h, s in zip(hs, sizes)]).to(out_device), torch.cat([c[:s] for c, s in zip(cs, sizes)]).to(out_device)
-
-
-def merge_runs_torch(hash_i64, count_i32):
-    """CPU/gloo reference merge (tests): exact unsigned order via numpy."""
-    h = hash_i64.cpu().numpy().view(np.uint64)
-    c = count_i32.cpu().numpy()
-    order = np.argsort(h, kind="stable")
-    h, c = h[order], c[order]
-    uh, idx = np.unique(h, return_index=True)
-    return uh, np.add.reduceat(c, idx).astype(np.int32) if h.size else c
-
-
-class ShardedSketch:
-    """One instance per rank. `ctx` is a dipgenie_amd.capi.Context bound to this rank's GPU."""
-
-    def __init__(self, ctx, device):
-        self.ctx, self.device = ctx, device
-
-    def local(self, bases_t, off_t, k, w):
-        """bases_t uint8 [n_bases] and off_t int64 [n+1] device tensors of THIS rank's reads."""
-        import ctypes as C
+    def __init__(self, ctx, device, stream=None):
         from . import capi
+        self.capi, self.ctx, self.device = capi, ctx, device
+        self.stream = stream if stream is not None else torch.cuda.Stream(device)
+        ctx.set_stream(self.stream.cuda_stream)
+
+    def sketch_reads(self, bases_t, off_t, k, w):
+        """bases_t uint8 [n_bases] and off_t int64 [n+1] device tensors of THIS rank's reads -> (hash int64, count int32)"""
         n_reads = off_t.numel() - 1
         cap = max(int(bases_t.numel()), 1)
         h = torch.empty(cap, dtype=torch.int64, device=self.device)
         c = torch.empty(cap, dtype=torch.int32, device=self.device)
         nd = C.c_int64()
-        capi._check(capi.lib.dg_sketch_reads_dev(self.ctx.h, bases_t.data_ptr(), off_t.data_ptr(), n_reads, bases_t.numel(), k, w,
-                                                 h.data_ptr(), c.data_ptr(), cap, C.byref(nd)), "dg_sketch_reads_dev")
+        self.capi._check(self.capi.lib.dg_sketch_reads_dev(self.ctx.h, bases_t.data_ptr(), off_t.data_ptr(), n_reads, bases_t.numel(), k, w,
+                                                           h.data_ptr(), c.data_ptr(), cap, C.byref(nd)), "dg_sketch_reads_dev")
         return h[: nd.value], c[: nd.value]
 
-    def dictionary_counts(self, dict_t, h, c):
-        """count[M] for the local shard, then all-reduce(sum) over ranks (RCCL)."""
-        from . import capi
+    def count_dictionary(self, dict_t, h, c):
         counts = torch.zeros(dict_t.numel(), dtype=torch.int32, device=self.device)
-        if counts.is_cuda:
-            torch.cuda.current_stream(self.device).synchronize()   # the zero fill is on torch's stream, the join on the ctx stream
-        capi._check(capi.lib.dg_sketch_count_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), c.data_ptr(),
-                                                            h.numel(), counts.data_ptr()), "dg_sketch_count_dictionary_dev")
-        self.ctx_sync()
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == "gloo":
-                host = counts.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                counts.copy_(host)
-            else:
-                dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        self.capi._check(self.capi.lib.dg_sketch_count_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), c.data_ptr(),
+                                                                      h.numel(), counts.data_ptr()), "dg_sketch_count_dictionary_dev")
         return counts
 
-    def global_spectrum(self, h, c):
-        """exact global (sorted distinct hash, #reads) on every rank"""
-        import ctypes as C
-        from . import capi
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
-            return h, c
-        hh, cc = allgather_runs(h, c, self.device)
-        if hh.is_cuda:
-            torch.cuda.synchronize(self.device)         # the collective ran on torch's stream, the merge runs on the ctx stream
-        oh = torch.empty_like(hh)
-        oc = torch.empty_like(cc)
+    def partition(self, h, world):
+        split = torch.empty(world + 1, dtype=torch.int64, device=self.device)
+        self.capi._check(self.capi.lib.dg_sketch_partition_dev(self.ctx.h, h.data_ptr(), h.numel(), world, split.data_ptr()), "dg_sketch_partition_dev")
+        return split
+
+    def merge_runs(self, h, c):
+        oh, oc = torch.empty_like(h), torch.empty_like(c)
         n = C.c_int64()
-        capi._check(capi.lib.dg_sketch_merge_runs_dev(self.ctx.h, hh.data_ptr(), cc.data_ptr(), hh.numel(), oh.data_ptr(), oc.data_ptr(),
-                                                      oh.numel(), C.byref(n)), "dg_sketch_merge_runs_dev")
+        self.capi._check(self.capi.lib.dg_sketch_merge_runs_dev(self.ctx.h, h.data_ptr(), c.data_ptr(), h.numel(), oh.data_ptr(), oc.data_ptr(),
+                                                                oh.numel(), C.byref(n)), "dg_sketch_merge_runs_dev")
         return oh[: n.value], oc[: n.value]
 
-    def ctx_sync(self):
-        from . import capi
-        capi._check(capi.lib.dg_synchronize(self.ctx.h), "dg_synchronize")
+    def rank_dictionary(self, dict_t, h, rank1):
+        self.capi._check(self.capi.lib.dg_sketch_rank_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), h.numel(), 0,
+                                                                     rank1.data_ptr()), "dg_sketch_rank_dictionary_dev")
+
+    def histogram(self, c, hist):
+        self.capi._check(self.capi.lib.dg_sketch_histogram_dev(self.ctx.h, c.data_ptr(), c.numel(), hist.numel(), hist.data_ptr()), "dg_sketch_histogram_dev")
+
+
+@dataclass
+class Score:
+    """what the scoring stage hands to the DP stage, identical on every rank except the sharded range"""
+    counts: torch.Tensor        # int32 [M]  #reads containing dictionary hash i (kmer_count restricted to D)
+    ids: torch.Tensor           # int64 [M]  global Sp_R id of dictionary hash i, -1 if no read has it
+    n_distinct: int             # count_sp_r: distinct read-minimizer hashes over all reads
+    hist: torch.Tensor          # int64 [HIST_BINS]  Hist_kmer: multiplicity -> #distinct hashes
+    range_hash: torch.Tensor    # int64 [n_r]  this rank's hash range of the global spectrum, sorted
+    range_count: torch.Tensor   # int32 [n_r]
+    range_base: int             # global id of range_hash[0]
+    range_sizes: list           # n_r of every rank
+
+
+class ShardedSketch:
+    """One instance per rank.  `ops`: HipOps (product) or a test shim with the same methods."""
+
+    def __init__(self, ops, device):
+        self.ops, self.device = ops, device
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.gloo = dist.is_initialized() and dist.get_backend() == "gloo"
+        self.stream = getattr(ops, "stream", None)
+
+    # gloo (CPU tests, one-GPU rehearsals) moves data through host tensors; RCCL works on the device tensors
+    def _c(self, t):
+        return t.cpu() if self.gloo and t.is_cuda else t
+
+    def _back(self, t):
+        return t.to(self.device) if t.device != torch.device(self.device) else t
+
+    def score(self, bases_t, off_t, dict_t, k, w):
+        """bases_t uint8 [n_bases], off_t int64 [n+1]: THIS rank's reads; dict_t int64 [M]: the sorted dictionary.
+        Runs on the ops' stream, ordered after whatever the caller has enqueued on its current stream and before
+        whatever it enqueues next."""
+        if self.stream is None:
+            return self._score(bases_t, off_t, dict_t, k, w)
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            out = self._score(bases_t, off_t, dict_t, k, w)
+        caller.wait_stream(self.stream)
+        return out
+
+    def _score(self, bases_t, off_t, dict_t, k, w):
+        ops, W, me = self.ops, self.world, self.rank
+        h, c = ops.sketch_reads(bases_t, off_t, k, w)
+        counts = ops.count_dictionary(dict_t, h, c)
+        work = None
+        if W > 1:                                        # (1) hit vector: asynchronous, overlaps the exchange
+            counts_c = self._c(counts)
+            work = dist.all_reduce(counts_c, op=dist.ReduceOp.SUM, async_op=True)
+        if W == 1:
+            rh, rc = h, c
+        else:                                            # (2) hash-range exchange
+            split = ops.partition(h, W)
+            send = self._c((split[1:] - split[:-1]).contiguous())
+            mat = torch.empty(W * W, dtype=torch.int64, device=send.device)
+            dist.all_gather_into_tensor(mat, send)       # world x world send-count matrix: the one size exchange
+            mat = mat.view(W, W).cpu()                   # the one host read of the exchange
+            in_splits, out_splits = mat[me].tolist(), mat[:, me].tolist()
+            payload = self._c(torch.stack([h, c.to(torch.int64)], dim=1).contiguous())     # [n, 2]: one collective for both columns
+            recv = torch.empty((sum(out_splits), 2), dtype=torch.int64, device=payload.device)
+            dist.all_to_all_single(recv, payload, output_split_sizes=out_splits, input_split_sizes=in_splits)
+            recv = self._back(recv)
+            rh, rc = ops.merge_runs(recv[:, 0].contiguous(), recv[:, 1].to(torch.int32).contiguous())
+        # (3) per-range distinct counts | multiplicity histogram | dictionary ids, one fused all-reduce
+        M = dict_t.numel()
+        tail = torch.zeros(W + HIST_BINS + M, dtype=torch.int64, device=self.device)
+        tail[me] = rh.numel()
+        ops.histogram(rc, tail[W: W + HIST_BINS])
+        ops.rank_dictionary(dict_t, rh, tail[W + HIST_BINS:])
+        if W > 1:
+            tail_c = self._c(tail)
+            dist.all_reduce(tail_c, op=dist.ReduceOp.SUM)
+            tail = self._back(tail_c)
+            work.wait()
+            counts = self._back(counts_c)
+        sizes = tail[:W]
+        base = torch.cumsum(sizes, 0) - sizes            # exclusive scan: first global id of every range
+        rank1 = tail[W + HIST_BINS:]
+        ids = torch.where(rank1 > 0, rank1 - 1 + base[hash_owner(dict_t, W)], torch.full_like(rank1, -1))
+        sizes_h = sizes.cpu().tolist()
+        return Score(counts=counts, ids=ids, n_distinct=int(sum(sizes_h)), hist=tail[W: W + HIST_BINS], range_hash=rh, range_count=rc,
+                     range_base=int(sum(sizes_h[:me])), range_sizes=sizes_h)
+
+    def gather_spectrum(self, sc):
+        """the whole global spectrum on every rank (sorted distinct hashes, #reads): ranges concatenated in rank order.
+        Not needed by the DP stage; for callers that want Sp_R replicated (and for the tests)."""
+        if self.world == 1:
+            return sc.range_hash, sc.range_count
+        m = max(max(sc.range_sizes), 1)
+        pad = torch.zeros((m, 2), dtype=torch.int64, device=self.device)
+        pad[: sc.range_hash.numel(), 0] = sc.range_hash
+        pad[: sc.range_hash.numel(), 1] = sc.range_count.to(torch.int64)
+        pad = self._c(pad)
+        out = torch.empty((self.world * m, 2), dtype=torch.int64, device=pad.device)
+        dist.all_gather_into_tensor(out, pad)
+        out = self._back(out).view(self.world, m, 2)
+        parts = [out[r, : sc.range_sizes[r]] for r in range(self.world)]
+        cat = torch.cat(parts)
+        return cat[:, 0].contiguous(), cat[:, 1].to(torch.int32).contiguous()

@@ -88,6 +88,9 @@ int dg_dp_solve_diploid(dg_ctx *, const dg_dp_graph *, dg_dp_result *);   /* = l
  * last run; out has n_levels entries, entry 0 unused. Requires dg_dp_set_option("digest",1). */
 int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
 int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
+/* measurement: which sweep kernel variants the last dg_dp_run launched, as "name:count name:count ..." (the names
+ * rocprofv3 reports, abbreviated); lets a profile taken in another process be matched against this run. */
+int dg_dp_get_launch_profile(dg_ctx *, char *buf, int cap);
 
 /* ---- (w,k)-minimizer sketching ---- */
 /* reads: concatenated bases + offsets [n_reads+1] (host). Outputs (malloc'ed by the library, release
@@ -122,6 +125,19 @@ int dg_sketch_count_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n
  * list with summed counts (device, capacity cap). Synchronises. */
 int dg_sketch_merge_runs_dev(dg_ctx *, const uint64_t *hash_dev, const int32_t *count_dev, int64_t n_total,
                              uint64_t *out_hash_dev, int32_t *out_count_dev, int64_t cap, int64_t *n_out);
+
+/* Read-sharded scoring across ranks (semantics of solver.cpp:526-555, 711-755): the uint64 hash space is
+ * cut into `world` equal ranges, rank r owns range r of the global spectrum.
+ *  dg_sketch_partition_dev: split_dev[r] (r = 0..world) = first index of the sorted list hash_dev[n] owned by a rank
+ *  >= r, i.e. the send offsets of the all-to-all of (hash,count) runs.  Asynchronous on the ctx stream. */
+int dg_sketch_partition_dev(dg_ctx *, const uint64_t *hash_dev, int64_t n, int world, int64_t *split_dev);
+/* rank1_dev[i] += base + idx + 1 for every dictionary hash that is entry idx of this rank's merged range hash_dev[n]
+ * (base = number of distinct read hashes in lower ranges): after a sum over ranks rank1 - 1 is the Sp_R id
+ * (solver.cpp:541-546), -1 = not a read minimizer.  Asynchronous on the ctx stream. */
+int dg_sketch_rank_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev, int64_t n,
+                                  int64_t base, int64_t *rank1_dev);
+/* hist_dev[min(count, n_bins-1)] += 1 per entry: this range's share of Hist_kmer (solver.cpp:745-755).  Asynchronous. */
+int dg_sketch_histogram_dev(dg_ctx *, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev);
 
 #ifdef __cplusplus
 }
