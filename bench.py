@@ -433,6 +433,7 @@ def main():
                 extra = [capi.Context(local_rank) for _ in range(n_inst - 1)]
                 for c2 in extra:
                     c2.dp_load_graph(g)
+                    c2.dp_run()                               # untimed: maps this instance's lattice chunks (seconds right after the CLI child freed its HBM)
                 every = [ctx] + extra
                 res = [None] * n_inst
 

@@ -38,7 +38,7 @@ struct Tile {
 };
 
 struct SketchState {
-    DevBuf d_bases, d_tiles, d_tile_cnt, d_tile_base, d_tile_sparse, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
+    DevBuf d_bases, d_off, d_seq_tiles, d_seq_wins, d_seq_tile0, d_seq_win0, d_tiles, d_tile_cnt, d_tile_base, d_tile_sparse, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
     dg_sketch_timing timing;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -254,6 +254,40 @@ __global__ __launch_bounds__(256) void compact_tiles_kernel(const int64_t *__res
     for (int64_t t = lane; t < n; t += 64) { dh[db + t] = sh[sb + t]; da[db + t] = sa[sb + t]; }
 }
 
+// Tile descriptors are built on the device from the sequence offsets (a million reads: no 8 MB offset download, no host
+// loop, no 32 MB descriptor upload per call).  seq_count: per sequence its tiles and windows; after exclusive scans of
+// both, seq_fill writes the descriptors and the sparse output offsets (a tile emits at most one minimizer per window).
+__global__ void seq_count_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, int64_t *__restrict__ ntile, int64_t *__restrict__ nwin) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seq) return;
+    int64_t nw = 0;
+    if (s < n_seq) nw = max((off[s + 1] - off[s]) - k - w + 2, (int64_t)0);      // solver.cpp:291 / 372: nothing if len < w+k-1
+    nwin[s] = nw;
+    ntile[s] = (nw + TW - 1) / TW;
+}
+__global__ __launch_bounds__(256) void seq_fill_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, const int64_t *__restrict__ tile_first,
+                                                       const int64_t *__restrict__ win_first, Tile *__restrict__ tiles, int64_t *__restrict__ sparse) {
+    // short sequences (reads: one tile each): one thread per sequence; a long one (a haplotype) is strided by the whole grid
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    if (n_seq == 1) {
+        const int64_t len = off[1] - off[0], nw = win_first[1];
+        for (int64_t t = tid; t < tile_first[1]; t += nth) {
+            tiles[t] = Tile{off[0], (int32_t)len, (int32_t)(t * TW), (int32_t)min((int64_t)TW, nw - t * TW), 0};
+            sparse[t] = t * TW;
+        }
+        if (tid == 0) sparse[tile_first[1]] = nw;
+        return;
+    }
+    for (int64_t s = tid; s <= n_seq; s += nth) {
+        if (s == n_seq) { sparse[tile_first[n_seq]] = win_first[n_seq]; break; }
+        const int64_t len = off[s + 1] - off[s], nw = win_first[s + 1] - win_first[s], t0 = tile_first[s];
+        for (int64_t q = 0; q * TW < nw; ++q) {
+            tiles[t0 + q] = Tile{off[s], (int32_t)len, (int32_t)(q * TW), (int32_t)min((int64_t)TW, nw - q * TW), (int32_t)s};
+            sparse[t0 + q] = win_first[s] + q * TW;
+        }
+    }
+}
+
 __global__ void pair_flag_kernel(const uint64_t *__restrict__ hash, const int64_t *__restrict__ seq, int64_t n, int32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -303,12 +337,32 @@ __global__ void dict_rank_kernel(const uint64_t *__restrict__ dict, int64_t n_di
     if (lo < n && hash[lo] == key) rank1[i] += base + lo + 1;
 }
 
-// hist[min(count, n_bins - 1)] += 1 per spectrum entry (solver.cpp:745-755 Hist_kmer, sharded)
-__global__ void mult_hist_kernel(const int32_t *__restrict__ cnt, int64_t n, int n_bins, unsigned long long *__restrict__ hist) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int m = min(max(cnt[i], 0), n_bins - 1);
-    atomicAdd(&hist[m], 1ULL);
+// hist[min(count, n_bins - 1)] += 1 per spectrum entry (solver.cpp:745-755 Hist_kmer, sharded).  Nearly all the mass sits
+// on a handful of small multiplicities: counts below 8 are tallied per lane in registers and reduced over the wave (one
+// global atomic per wave and bin), the rest goes through a workgroup-private LDS histogram.
+constexpr int HIST_LDS = 4096;
+__global__ __launch_bounds__(256) void mult_hist_kernel(const int32_t *__restrict__ cnt, int64_t n, int n_bins, unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int lh[HIST_LDS];
+    for (int q = threadIdx.x; q < HIST_LDS; q += 256) lh[q] = 0;
+    __syncthreads();
+    unsigned int low[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = min(max(cnt[i], 0), n_bins - 1);
+        if (m < 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) low[q] += m == q ? 1u : 0u;
+        } else if (m < HIST_LDS) atomicAdd(&lh[m], 1u);
+        else atomicAdd(&hist[m], 1ULL);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned int v = low[q];
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_down(v, sft);
+        if ((threadIdx.x & 63) == 0 && v && q < n_bins) atomicAdd(&hist[q], (unsigned long long)v);
+    }
+    __syncthreads();
+    for (int q = 8 + threadIdx.x; q < HIST_LDS && q < n_bins; q += 256)
+        if (lh[q]) atomicAdd(&hist[q], (unsigned long long)lh[q]);
 }
 
 // ------------------------------------------------------------------ host side
@@ -322,34 +376,36 @@ static size_t lds_per_wave(int k, int w) {
     return (b + 15) & ~(size_t)15;
 }
 
-static void make_tiles(const int64_t *off, int64_t n_seq, int k, int w, std::vector<Tile> &tiles) {
-    tiles.clear();
-    for (int64_t s = 0; s < n_seq; ++s) {
-        const int64_t len = off[s + 1] - off[s];
-        const int64_t nwin = len - k - w + 2;           // solver.cpp:291 / 372: nothing if len < w+k-1
-        for (int64_t w0 = 0; w0 < nwin; w0 += TW)
-            tiles.push_back(Tile{off[s], (int32_t)len, (int32_t)w0, (int32_t)std::min<int64_t>(TW, nwin - w0), (int32_t)s});
-    }
-}
-
-// Runs the tile kernel (+ compaction) over device-resident bases. On return d_hash/d_aux hold n_emit entries.
+// Runs the tile kernel (+ compaction) over device-resident bases and sequence offsets. On return d_hash/d_aux hold n_emit entries.
 template <bool AUX_IS_POS>
-static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &tiles, int k, int w, int64_t *n_emit) {
+static int run_tiles(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_emit) {
     SketchState &S = state(c);
     hipStream_t s = c->stream;
-    const int64_t nt = (int64_t)tiles.size();
     *n_emit = 0;
+    if (n_seq <= 0) return DG_OK;
+    // per-sequence tile / window counts and their exclusive scans (entry n_seq = totals)
+    if (int rc = S.d_seq_tiles.ensure(8 * (size_t)(n_seq + 1))) return rc;
+    if (int rc = S.d_seq_wins.ensure(8 * (size_t)(n_seq + 1))) return rc;
+    if (int rc = S.d_seq_tile0.ensure(8 * (size_t)(n_seq + 1))) return rc;
+    if (int rc = S.d_seq_win0.ensure(8 * (size_t)(n_seq + 1))) return rc;
+    hipLaunchKernelGGL(seq_count_kernel, dim3((unsigned)((n_seq + 1 + 255) / 256)), dim3(256), 0, s, off_dev, n_seq, k, w, S.d_seq_tiles.as<int64_t>(), S.d_seq_wins.as<int64_t>());
+    size_t tb = 0;
+    DG_HIP(rocprim::exclusive_scan(nullptr, tb, S.d_seq_tiles.as<int64_t>(), S.d_seq_tile0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
+    if (int rc = S.d_tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_tiles.as<int64_t>(), S.d_seq_tile0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
+    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_wins.as<int64_t>(), S.d_seq_win0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
+    int64_t tot[2] = {0, 0};
+    DG_HIP(hipMemcpyAsync(&tot[0], S.d_seq_tile0.as<int64_t>() + n_seq, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(&tot[1], S.d_seq_win0.as<int64_t>() + n_seq, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipStreamSynchronize(s));
+    const int64_t nt = tot[0], n_win = tot[1];
     if (nt == 0) return DG_OK;
     if (int rc = S.d_tiles.ensure(sizeof(Tile) * nt)) return rc;
-    DG_HIP(hipMemcpyAsync(S.d_tiles.p, tiles.data(), sizeof(Tile) * nt, hipMemcpyHostToDevice, s));
     if (int rc = S.d_tile_cnt.ensure(8 * (nt + 1))) return rc;
     if (int rc = S.d_tile_base.ensure(8 * (nt + 1))) return rc;
     if (int rc = S.d_tile_sparse.ensure(8 * (nt + 1))) return rc;
-    // sparse offsets: a tile emits at most one minimizer per window
-    std::vector<int64_t> sparse((size_t)nt + 1, 0);
-    for (int64_t t = 0; t < nt; ++t) sparse[t + 1] = sparse[t] + tiles[t].nwin;
-    const int64_t n_win = sparse[nt];
-    DG_HIP(hipMemcpyAsync(S.d_tile_sparse.p, sparse.data(), 8 * (size_t)(nt + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(seq_fill_kernel, dim3((unsigned)std::min<int64_t>(((n_seq == 1 ? nt : n_seq + 1) + 255) / 256, 4096)), dim3(256), 0, s, off_dev, n_seq, k, w,
+                       S.d_seq_tile0.as<int64_t>(), S.d_seq_win0.as<int64_t>(), S.d_tiles.as<Tile>(), S.d_tile_sparse.as<int64_t>());
     if (int rc = S.d_hash2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;     // sparse output (dead before the sort reuses them)
     if (int rc = S.d_aux2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;
     const size_t lpw = lds_per_wave(k, w);
@@ -358,14 +414,13 @@ static int run_tiles(dg_ctx *c, const char *bases_dev, const std::vector<Tile> &
                        S.d_tile_cnt.as<int64_t>(), S.d_tile_sparse.as<int64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), (int)lpw);
     // exclusive scan of counts (as int64) -> tile_base; total at [nt]
     DG_HIP(hipMemsetAsync((char *)S.d_tile_cnt.p + 8 * nt, 0, 8, s));
-    size_t tb = 0;
     const int64_t *in = S.d_tile_cnt.as<int64_t>();
     DG_HIP(rocprim::exclusive_scan(nullptr, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
     if (int rc = S.d_tmp.ensure(tb)) return rc;
     DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
     int64_t total = 0;
     DG_HIP(hipMemcpyAsync(&total, S.d_tile_base.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, s));
-    DG_HIP(hipStreamSynchronize(s));                                 // (also keeps `sparse` alive long enough)
+    DG_HIP(hipStreamSynchronize(s));
     *n_emit = total;
     if (total == 0) return DG_OK;
     if (int rc = S.d_hash.ensure(8 * total)) return rc;
@@ -420,14 +475,12 @@ static int events(SketchState &S) {
     return DG_OK;
 }
 
-static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *off_host, int64_t n_reads, int k, int w, int64_t *n_distinct) {
+static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_reads, int k, int w, int64_t *n_distinct) {
     SketchState &S = state(c);
     if (int rc = events(S)) return rc;
-    std::vector<Tile> tiles;
-    make_tiles(off_host, n_reads, k, w, tiles);
     DG_HIP(hipEventRecord(S.ev[0], c->stream));
     int64_t n_emit = 0;
-    if (int rc = run_tiles<false>(c, bases_dev, tiles, k, w, &n_emit)) return rc;
+    if (int rc = run_tiles<false>(c, bases_dev, off_dev, n_reads, k, w, &n_emit)) return rc;
     DG_HIP(hipEventRecord(S.ev[1], c->stream));
     if (int rc = spectrum_from_pairs(c, n_emit, n_distinct)) return rc;
     DG_HIP(hipEventRecord(S.ev[2], c->stream));
@@ -452,8 +505,10 @@ extern "C" int dg_sketch_reads(dg_ctx *c, const char *bases, const int64_t *read
     const int64_t nb = n_reads ? read_off[n_reads] : 0;
     if (int rc = S.d_bases.ensure((size_t)nb + 16)) return rc;
     if (nb) DG_HIP(hipMemcpyAsync(S.d_bases.p, bases, (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    if (int rc = S.d_off.ensure(8 * (size_t)(n_reads + 1))) return rc;
+    if (n_reads) DG_HIP(hipMemcpyAsync(S.d_off.p, read_off, 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, c->stream));
     int64_t nd = 0;
-    if (int rc = sketch_reads_device(c, S.d_bases.as<char>(), read_off, n_reads, k, w, &nd)) return rc;
+    if (int rc = sketch_reads_device(c, S.d_bases.as<char>(), S.d_off.as<int64_t>(), n_reads, k, w, &nd)) return rc;
     *hash = (uint64_t *)malloc(8 * (size_t)(nd + 1));
     *cnt = (int32_t *)malloc(4 * (size_t)(nd + 1));
     if (!*hash || !*cnt) { set_error("host malloc failed"); return DG_ERR_OOM; }
@@ -472,11 +527,8 @@ extern "C" int dg_sketch_reads_dev(dg_ctx *c, const char *bases_dev, const int64
     if (int rc = check_kw(k, w)) return rc;
     if (!bases_dev || !read_off_dev || !n_distinct || n_reads < 0) { set_error("dg_sketch_reads_dev: bad arguments"); return DG_ERR_ARG; }
     (void)n_bases;
-    std::vector<int64_t> off((size_t)n_reads + 1);
-    DG_HIP(hipMemcpyAsync(off.data(), read_off_dev, 8 * off.size(), hipMemcpyDeviceToHost, c->stream));
-    DG_HIP(hipStreamSynchronize(c->stream));
     int64_t nd = 0;
-    if (int rc = sketch_reads_device(c, bases_dev, off.data(), n_reads, k, w, &nd)) return rc;
+    if (int rc = sketch_reads_device(c, bases_dev, read_off_dev, n_reads, k, w, &nd)) return rc;
     if (nd > cap) { set_error("dg_sketch_reads_dev: %lld distinct hashes exceed capacity %lld", (long long)nd, (long long)cap); return DG_ERR_ARG; }
     SketchState &S = state(c);
     if (nd) {
@@ -497,12 +549,12 @@ extern "C" int dg_sketch_haplotype(dg_ctx *c, const char *seq, int64_t len, int 
     if (int rc = events(S)) return rc;
     if (int rc = S.d_bases.ensure((size_t)len + 16)) return rc;
     if (len) DG_HIP(hipMemcpyAsync(S.d_bases.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
-    int64_t off[2] = {0, len};
-    std::vector<Tile> tiles;
-    make_tiles(off, 1, k, w, tiles);
+    const int64_t off[2] = {0, len};
+    if (int rc = S.d_off.ensure(16)) return rc;
+    DG_HIP(hipMemcpyAsync(S.d_off.p, off, 16, hipMemcpyHostToDevice, c->stream));
     DG_HIP(hipEventRecord(S.ev[0], c->stream));
     int64_t ne = 0;
-    if (int rc = run_tiles<true>(c, S.d_bases.as<char>(), tiles, k, w, &ne)) return rc;
+    if (int rc = run_tiles<true>(c, S.d_bases.as<char>(), S.d_off.as<int64_t>(), 1, k, w, &ne)) return rc;
     DG_HIP(hipEventRecord(S.ev[1], c->stream));
     *hash = (uint64_t *)malloc(8 * (size_t)(ne + 1));
     *pos = (int64_t *)malloc(8 * (size_t)(ne + 1));
@@ -601,7 +653,7 @@ extern "C" int dg_sketch_histogram_dev(dg_ctx *c, const int32_t *count_dev, int6
     if (int rc = bind(c)) return rc;
     if (n_bins < 2 || !hist_dev) { set_error("dg_sketch_histogram_dev: bad arguments"); return DG_ERR_ARG; }
     if (n <= 0) return DG_OK;
-    hipLaunchKernelGGL(mult_hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, count_dev, n, n_bins, (unsigned long long *)hist_dev);
+    hipLaunchKernelGGL(mult_hist_kernel, dim3((unsigned)std::min<int64_t>((n + 4095) / 4096, 1024)), dim3(256), 0, c->stream, count_dev, n, n_bins, (unsigned long long *)hist_dev);
     DG_HIP(hipGetLastError());
     return DG_OK;
 }

@@ -9,7 +9,10 @@ g = capi.DpGraphArrays.load(sys.argv[1])
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 ctxs = [capi.Context(0) for _ in range(N)]
-for c in ctxs: c.dp_load_graph(g)
+for c in ctxs:
+    for kv in os.environ.get("DG_OPTS", "").split(","):          # e.g. DG_OPTS="rowx=0,coop=0"
+        if kv: c.dp_set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    c.dp_load_graph(g)
 outs = [None] * N
 def work(q):
     for _ in range(reps): outs[q] = ctxs[q].dp_run()
