@@ -122,7 +122,9 @@ def reference_baseline(cache, workload, bench_gfa, device):
                         "sample": f"reference binary -t{cores} -p2 -R18 on the first 1 % of the bench panel cut out as its own panel (24 walks, "
                                   f"{info['hap_bp'][0]} bp, {ours['n_levels']} levels, {ours['cells']} cells, {info['n_reads']} reads): its DP function took "
                                   f"{dp_s:.2f} s of {wall:.1f} s end to end; FASTA identical to the GPU run on the same sample (md5 {md5[:8]}). "
-                                  "The whole bench workload took the same binary 731.8 s of DP (51 M cells/s, 8 threads, build container; DESIGN.md section 6)"}
+                                  f"Threads: {cores} = this box's CPU share (north_star names a 32-thread baseline; no 32-core host is available to this run). "
+                                  "The WHOLE bench workload takes the same binary 354.6 s of DP (105 M cells/s) and 483.9 s end to end at 8 threads "
+                                  "in the build container (round-2 run, FASTA md5 cd13930a = the GPU run's; DESIGN.md section 6)"}
         except Exception as e:                              # noqa: BLE001 - any failure: next fallback
             log(f"prefix-panel reference baseline failed ({e!r}); falling back to MHC_4")
     gfa, reads = (os.path.join(ROOT, "tests", "data", n) for n in ("MHC_4.gfa.gz", "CHM13_reads.fq.gz"))
