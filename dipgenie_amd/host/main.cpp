@@ -86,8 +86,8 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i)
         if (!strcmp(argv[i], "--version")) { fprintf(stderr, "PHI version: 1.0 (dipgenie-mi355x)\n"); return 0; }
     int c;
-    // reference option string: "x:p:d:c:l:s:m:R:P:a:q:T:H:N:m:h:k:w:t:g:r:o:DSc" (main.cpp:39); -G -J -D are ours
-    while ((c = getopt(argc, argv, "x:p:d:c:l:s:m:R:P:a:q:T:H:N:h:k:w:t:g:r:o:G:J:D:")) >= 0) {
+    // reference option string: "x:p:d:c:l:s:m:R:P:a:q:T:H:N:m:h:k:w:t:g:r:o:DSc" (main.cpp:39); -G -J -D -A -X are ours
+    while ((c = getopt(argc, argv, "x:p:d:c:l:s:m:R:P:a:q:T:H:N:h:k:w:t:g:r:o:G:J:D:A:X")) >= 0) {
         switch (c) {
         case 'w': p.opt.w = atoi(optarg); break;
         case 'k': p.opt.k = atoi(optarg); break;
@@ -103,6 +103,8 @@ int main(int argc, char **argv) {
         case 'G': device = atoi(optarg); break;
         case 'J': json = optarg; break;
         case 'D': p.opt.dump_prefix = optarg; break;
+        case 'A': p.opt.anchor_dump = optarg; break;
+        case 'X': p.opt.dump_only = true; break;
         default: break;   // parsed-but-unused on this path
         }
     }
@@ -123,6 +125,7 @@ int main(int argc, char **argv) {
     int rc = p.run(err);
     dg_ctx *ctx = g_lazy.get();
     if (!ctx) { fprintf(stderr, "[E::main] %s\n", g_lazy.err.c_str()); return 2; }   // no gfx950 device: no CPU fallback
+    if (rc != 0 && err == "dump_only") { std::cout.flush(); fflush(nullptr); _exit(0); }   // -X: stop after the dump(s)
     if (rc != 0) { fprintf(stderr, "[E::main] %s\n", err.c_str()); dg_destroy(ctx); return 1; }
     dg_dp_timing tm;
     if (p.opt.ploidy == 2 && dg_dp_get_timing(ctx, &tm) == DG_OK)

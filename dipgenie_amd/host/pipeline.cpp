@@ -1241,6 +1241,20 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     return 0;
 }
 
+// "id hap v0,v1,..." per occurrence in Anchor_hits order (id asc, hap asc, occurrence order), then "homo id" per set bit of
+// homo_bv: the format oracle/ref_harness.cpp dumps from the reference's own Solver object (tests/golden/anchors.json)
+bool Pipeline::dump_anchors(const std::string &path) const {
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    for (const Occ &o : occs) {
+        fprintf(f, "%d %d ", o.a, o.h);
+        for (uint32_t q = 0; q < o.len; ++q) fprintf(f, "%s%d", q ? "," : "", vpool[o.off + q]);
+        fputc('\n', f);
+    }
+    for (size_t id = 0; id < homo_bv.size(); ++id) if (homo_bv[id]) fprintf(f, "homo %zu\n", id);
+    return fclose(f) == 0;
+}
+
 int Pipeline::run(std::string &err) {                                  // main.cpp:117-165
     sum = Summary();
     opt.threads = std::max(1, opt.threads);                            // -t0 / negative: every num_threads clause below sees a valid count
@@ -1255,6 +1269,10 @@ int Pipeline::run(std::string &err) {                                  // main.c
     }
     if (load_reads(err)) return -1;
     if (compute_and_classify_anchors(err)) return -1;
+    if (!opt.anchor_dump.empty()) {
+        if (!dump_anchors(opt.anchor_dump)) { err = "cannot write " + opt.anchor_dump; return -1; }
+        if (opt.dump_only && opt.dump_prefix.empty()) { err = "dump_only"; return -1; }
+    }
     if (solve(err)) return -1;
     sum.stage_s.emplace_back("total", now_s() - t0);
     return 0;

@@ -46,6 +46,8 @@ struct Options {
     std::string gfa_file, reads_file, hap_file;   // -g -r -o
     std::string dump_prefix;  // (ours) if set, dump the levelized DP graph to <prefix>.dpg
     bool dump_only = false;   // (ours, tests) stop after the dump
+    std::string anchor_dump;  // (ours, tests) if set, write Anchor_hits + homo_bv as text (format of oracle/ref_harness.cpp `anchors`)
+    bool host_anchors = false;   // (ours, tests) keep the anchor join / filter / sort on the host even if the backend offers it
 };
 
 // ExpandedGraph.hpp:16-26, flattened: CSR adjacency (per-vertex order = the reference's push order),
@@ -148,6 +150,7 @@ class Pipeline {
     int compute_and_classify_anchors(std::string &err);
     int solve(std::string &err);           // Approximator::solve (writes the FASTA)
     int run(std::string &err);             // main.cpp:117-165
+    bool dump_anchors(const std::string &path) const;
 
     // exposed for tests
     DpGraphStorage dpg;

@@ -7,12 +7,16 @@
 //   ref_harness hashes K W  < seqs.txt       -> Solver::compute_hashes per line (sorted set, hex)
 //   ref_harness minimizers K W < seqs.txt    -> Solver::index_kmers per line (emitted hashes in order)
 //   ref_harness fit < hist.txt               -> KGFitterBO::fit + classify ("mult freq" per line)
+//   ref_harness anchors K W T THREADS GFA READS -> Solver::read_gfa + read_ip_reads + compute_and_classify_anchors
+//                                               (solver.cpp:27-245, 449-887), then Anchor_hits (solver.h:84) one line per
+//                                               occurrence "id hap v0,v1,...", followed by "homo <id>" lines of homo_bv
 #include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <string>
 
 #include "solver.h"
+#include "gfa.h"
 #include "Classifier.hpp"
 #include "Fitter.hpp"
 
@@ -46,6 +50,29 @@ int main(int argc, char **argv) {
             }
             printf("\n");
         }
+        return 0;
+    }
+    if (mode == "anchors" && argc >= 8) {
+        gfa_t *g = gfa_read(argv[6]);
+        if (!g) return 2;
+        Solver s(g);
+        s.read_gfa();
+        s.k_mer = atoi(argv[2]); s.window = atoi(argv[3]); s.threshold = (float)atof(argv[4]); s.num_threads = atoi(argv[5]);
+        s.bucket_bits = 14; s.max_occ = 5000; s.debug = false;
+        std::vector<std::pair<std::string, std::string>> reads;
+        s.read_ip_reads(reads, argv[7]);
+        s.compute_and_classify_anchors(reads);
+        FILE *out = argc > 8 ? fopen(argv[8], "w") : stdout;
+        for (size_t id = 0; id < s.Anchor_hits.size(); ++id)
+            for (size_t h = 0; h < s.Anchor_hits[id].size(); ++h)
+                for (auto &occ : s.Anchor_hits[id][h]) {
+                    if (occ.empty()) continue;
+                    fprintf(out, "%zu %zu ", id, h);
+                    for (size_t q = 0; q < occ.size(); ++q) fprintf(out, "%s%d", q ? "," : "", occ[q]);
+                    fputc('\n', out);
+                }
+        for (size_t id = 0; id < s.homo_bv.size(); ++id) if (s.homo_bv[id]) fprintf(out, "homo %zu\n", id);
+        if (out != stdout) fclose(out);
         return 0;
     }
     if (mode == "fit") {

@@ -150,7 +150,7 @@ def e2e():
     cases["mhc24_p2"] = dict(gfa="<synth.ensure_mhc24>", reads="<synth.ensure_mhc24>", args=["-p2", "-R18"],
                              fasta_md5="cd13930ac90651b7e441506c1ecd4514", dp_value=331848, r1=10, r2=8, len1=5042783, len2=5032337, obj=64156,
                              slow=True, note="reference (oracle/_ref/DipGenie_ref -t8) on dipgenie_amd.synth.mosaic_panel(seed=24, "
-                             "read_seed=4): 892.6 s wall, DP 731.8 s, RSS 9.8 GB")
+                             "read_seed=4): 483.9 s wall, DP 354.6 s, RSS 9.8 GB (round 2; 892.6 / 731.8 s on a busy box in round 1)")
     # BASELINE configs[1] as written needs test/HG002.mhc.2x.fq.gz, which the reference tree does not ship
     # (.MISSING_LARGE_BLOBS): seeded 2x reads from the two HG002 walks instead; reference run in this container (-t8)
     cases["mhc4_hg002_2x"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="<synth.ensure_mhc4_hg002>", args=["-p2", "-R18"],
@@ -162,6 +162,42 @@ def e2e():
     cases["mhc4_p1"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p1"],
                             fasta_md5="0c4df87ded10634a36db0a2c90521ff0", best_r_haploid=0, spectrum=138834, slow=True)
     return cases
+
+
+def anchors(cases):
+    """Anchor_hits + homo_bv of the REAL reference (ref_harness anchors = Solver::read_gfa + read_ip_reads +
+    compute_and_classify_anchors, solver.cpp:27-245, 449-887) for every e2e case with inputs on disk: the text dump
+    ("id hap v0,v1,..." per occurrence in Anchor_hits order, then "homo id" lines), its sha256 and counts; dumps below
+    64 KB are committed verbatim."""
+    out = {}
+    seen = {}
+    for name, c in cases.items():
+        if c["gfa"].startswith("<"):
+            continue
+        reads = c["reads"]
+        if reads == "<synth.ensure_mhc4_hg002>":
+            reads = os.path.relpath(synth.ensure_mhc4_hg002("/tmp/dg_golden_hg002")[1], ROOT)
+        k = next((a[2:] for a in c["args"] if a.startswith("-k")), "31")
+        w = next((a[2:] for a in c["args"] if a.startswith("-w")), "25")
+        T = next((a[2:] for a in c["args"] if a.startswith("-T")), "1.0")
+        key = (c["gfa"], reads, k, w, T)
+        if key in seen:                                   # -p1 / -p2 / -R variants share the anchor stage
+            out[name] = dict(same_as=seen[key])
+            continue
+        seen[key] = name
+        with tempfile.TemporaryDirectory() as td:
+            dump = os.path.join(td, "a.txt")
+            sh([HARNESS, "anchors", k, w, T, "8", os.path.join(ROOT, c["gfa"]), os.path.join(ROOT, reads) if not os.path.isabs(reads) else reads, dump])
+            txt = open(dump).read()
+        lines = txt.splitlines()
+        occ = [l for l in lines if not l.startswith("homo")]
+        d = dict(k=int(k), w=int(w), T=float(T), n_occ=len(occ), n_ids=len({l.split()[0] for l in occ}), n_homo=len(lines) - len(occ),
+                 sha256=hashlib.sha256(txt.encode()).hexdigest())
+        if len(txt) < 65536:
+            d["dump"] = lines
+        out[name] = d
+        print("anchors", name, d["n_occ"], d["n_ids"], d["n_homo"], d["sha256"][:12], flush=True)
+    return out
 
 
 def dpg():
@@ -183,6 +219,8 @@ if __name__ == "__main__":
         json.dump(kat_sketch(), open(os.path.join(HERE, "kat_sketch.json"), "w"), indent=0)
     if "e2e" in what:
         json.dump(e2e(), open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+    if "anchors" in what:
+        json.dump(anchors(json.load(open(os.path.join(HERE, "e2e.json")))), open(os.path.join(HERE, "anchors.json"), "w"), indent=0)
     if "dpg" in what:
         dpg()
     if "fit" in what:

@@ -5,7 +5,7 @@
 // a GPU, that the HOST stages (GFA reader, read_gfa order, anchors/filter, fit/classify, expanded
 // graph, levelize, traceback, FASTA writer) reproduce the reference byte-for-byte, and dump the
 // levelized DP graph (.dpg) that the GPU parity tests feed to both the oracle and the HIP path.
-// Same flags as the product CLI, plus -D <prefix> (dump) and -J <file> (JSON summary).
+// Same flags as the product CLI, plus -D <prefix> (dump) and -J <file> (JSON summary), -A <file> (Anchor_hits dump).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
     dg::Pipeline p;
     std::string json;
     int c;
-    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:qXC:")) >= 0) {
+    while ((c = getopt(argc, argv, "t:p:R:g:r:o:k:w:T:d:D:J:qXC:A:")) >= 0) {
         switch (c) {
         case 't': p.opt.threads = atoi(optarg); break;
         case 'p': p.opt.ploidy = atoi(optarg); break;
@@ -104,6 +104,7 @@ int main(int argc, char **argv) {
         case 'q': p.opt.quiet = true; break;
         case 'X': p.opt.dump_only = true; break;
         case 'C': g_cache = optarg; break;
+        case 'A': p.opt.anchor_dump = optarg; break;
         }
     }
     p.be.sketch_reads = o_sketch_reads;
