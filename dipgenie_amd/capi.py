@@ -51,6 +51,7 @@ SYMBOLS = [
     "dg_dp_set_option", "dg_dp_get_launch_profile", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
+    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -85,6 +86,16 @@ lib.dg_sketch_merge_runs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c
 lib.dg_sketch_partition_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 lib.dg_sketch_rank_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
 lib.dg_sketch_histogram_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+
+
+class AnchorResult(C.Structure):
+    _fields_ = [("n_occ", C.c_int64), ("n_vtx", C.c_int64), ("occ_id", C.c_void_p), ("occ_hap", C.c_void_p), ("occ_off", C.c_void_p),
+                ("occ_len", C.c_void_p), ("vpool", C.c_void_p), ("n_candidates", C.c_int64), ("n_unstable_groups", C.c_int64)]
+
+
+lib.dg_anchor_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int]
+lib.dg_anchor_add_haplotype.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+lib.dg_anchor_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.POINTER(AnchorResult)]
 
 
 class DgError(RuntimeError):

@@ -53,6 +53,7 @@ extern "C" void dg_destroy(dg_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     dgi::dp_state_free(c->dp);
     dgi::sketch_state_free(c->sk);
+    dgi::anchor_state_free(c->an);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -40,8 +40,9 @@ struct DevBuf {                       // owning device allocation
     template <class T> T *as() const { return (T *)p; }
 };
 
-struct DpState;       // dg_dp.hip
+struct DpState;       // dg_dp_*.hip
 struct SketchState;   // dg_sketch.hip
+struct AnchorState;   // dg_anchor.hip
 
 }  // namespace dgi
 
@@ -52,11 +53,15 @@ struct dg_ctx {
     hipDeviceProp_t prop;
     dgi::DpState *dp = nullptr;
     dgi::SketchState *sk = nullptr;
+    dgi::AnchorState *an = nullptr;
 };
 
 namespace dgi {
 void dp_state_free(DpState *);
 void sketch_state_free(SketchState *);
+void anchor_state_free(AnchorState *);
+// dg_sketch.hip: minimizer list of one haplotype left on the device (valid until the next sketch call on the ctx)
+int sketch_haplotype_dev(dg_ctx *c, const char *seq, int64_t len, int k, int w, const uint64_t **hash_dev, const int64_t **pos_dev, int64_t *n);
 inline int bind(dg_ctx *c) {
     if (!c) { set_error("null ctx"); return DG_ERR_ARG; }
     hipError_t e = hipSetDevice(c->device);

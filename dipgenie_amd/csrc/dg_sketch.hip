@@ -540,10 +540,12 @@ extern "C" int dg_sketch_reads_dev(dg_ctx *c, const char *bases_dev, const int64
     return DG_OK;
 }
 
-extern "C" int dg_sketch_haplotype(dg_ctx *c, const char *seq, int64_t len, int k, int w, uint64_t **hash, int64_t **pos, int64_t *n) {
-    if (int rc = bind(c)) return rc;
+// minimizer list of one haplotype, left on the device: (hash, position of the winning k-mer) in sequence order.  The
+// pointers stay valid until the next sketch call on this ctx.  kernel_ms is recorded in the ctx's sketch timing.
+namespace dgi {
+int sketch_haplotype_dev(dg_ctx *c, const char *seq, int64_t len, int k, int w, const uint64_t **hash_dev, const int64_t **pos_dev, int64_t *n) {
     if (int rc = check_kw(k, w)) return rc;
-    if (!hash || !pos || !n || len < 0) { set_error("dg_sketch_haplotype: bad arguments"); return DG_ERR_ARG; }
+    if (len < 0) { set_error("sketch_haplotype: negative length"); return DG_ERR_ARG; }
     if (len >= ((int64_t)1 << 31)) { set_error("sequence longer than 2^31 bases is not supported"); return DG_ERR_UNSUPPORTED; }
     SketchState &S = state(c);
     if (int rc = events(S)) return rc;
@@ -556,16 +558,27 @@ extern "C" int dg_sketch_haplotype(dg_ctx *c, const char *seq, int64_t len, int 
     int64_t ne = 0;
     if (int rc = run_tiles<true>(c, S.d_bases.as<char>(), S.d_off.as<int64_t>(), 1, k, w, &ne)) return rc;
     DG_HIP(hipEventRecord(S.ev[1], c->stream));
+    DG_HIP(hipStreamSynchronize(c->stream));
+    DG_HIP(hipEventElapsedTime(&S.timing.kernel_ms, S.ev[0], S.ev[1]));
+    S.timing.sort_ms = 0; S.timing.total_ms = S.timing.kernel_ms; S.timing.n_emitted = ne;
+    *hash_dev = S.d_hash.as<uint64_t>(); *pos_dev = S.d_aux.as<int64_t>(); *n = ne;
+    return DG_OK;
+}
+}  // namespace dgi
+
+extern "C" int dg_sketch_haplotype(dg_ctx *c, const char *seq, int64_t len, int k, int w, uint64_t **hash, int64_t **pos, int64_t *n) {
+    if (int rc = bind(c)) return rc;
+    if (!hash || !pos || !n) { set_error("dg_sketch_haplotype: bad arguments"); return DG_ERR_ARG; }
+    const uint64_t *hd = nullptr; const int64_t *pd = nullptr; int64_t ne = 0;
+    if (int rc = sketch_haplotype_dev(c, seq, len, k, w, &hd, &pd, &ne)) return rc;
     *hash = (uint64_t *)malloc(8 * (size_t)(ne + 1));
     *pos = (int64_t *)malloc(8 * (size_t)(ne + 1));
     if (!*hash || !*pos) { set_error("host malloc failed"); return DG_ERR_OOM; }
     if (ne) {
-        DG_HIP(hipMemcpyAsync(*hash, S.d_hash.p, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
-        DG_HIP(hipMemcpyAsync(*pos, S.d_aux.p, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipMemcpyAsync(*hash, hd, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipMemcpyAsync(*pos, pd, 8 * (size_t)ne, hipMemcpyDeviceToHost, c->stream));
+        DG_HIP(hipStreamSynchronize(c->stream));
     }
-    DG_HIP(hipStreamSynchronize(c->stream));
-    DG_HIP(hipEventElapsedTime(&S.timing.kernel_ms, S.ev[0], S.ev[1]));
-    S.timing.sort_ms = 0; S.timing.total_ms = S.timing.kernel_ms; S.timing.n_emitted = ne;
     *n = ne;
     return DG_OK;
 }

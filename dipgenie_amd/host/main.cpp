@@ -53,6 +53,18 @@ static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) {
     dg_ctx *x = ((LazyCtx *)c)->get();
     return x ? dg_dp_solve_diploid(x, g, r) : DG_ERR_NO_DEVICE;
 }
+static int b_anchor_begin(void *c, int32_t nh, int32_t nv, const int32_t *top, int k, int w) {
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_anchor_begin(x, nh, nv, top, k, w) : DG_ERR_NO_DEVICE;
+}
+static int b_anchor_add(void *c, int32_t h, const char *s, int64_t len, const int32_t *sv, const int64_t *ss, int64_t ns, int64_t *n) {
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_anchor_add_haplotype(x, h, s, len, sv, ss, ns, n) : DG_ERR_NO_DEVICE;
+}
+static int b_anchor_finish(void *c, const uint64_t *sp, int64_t n, float thr, dg_anchor_result *out) {
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_anchor_finish(x, sp, n, thr, out) : DG_ERR_NO_DEVICE;
+}
 static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reservation (2 B/cell) with the host stages
     dg_ctx *x = ((LazyCtx *)c)->get();
     const double bytes = 2.0 * (double)est_cells;     // a low estimate is harmless: the rest is mapped before the sweep starts
@@ -120,6 +132,10 @@ int main(int argc, char **argv) {
     p.be.dp_solve_diploid = b_dp;
     p.be.free_buf = dg_free;
     p.be.hint_dp_soon = b_hint;
+    p.be.anchor_begin = b_anchor_begin;
+    p.be.anchor_add_haplotype = b_anchor_add;
+    p.be.anchor_finish = b_anchor_finish;
+    if (getenv("DG_HOST_ANCHORS")) p.opt.host_anchors = true;   // A/B and parity runs: the host join / filter / sort
     p.be.last_error = b_last_error;
     std::string err;
     int rc = p.run(err);

@@ -171,6 +171,11 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     double t_sketch = 0;
     int rc_sketch = 0;
     std::string err_sketch;
+    // Device path: the backend keeps every haplotype's minimizers and vertex lists on the device
+    // (dg_anchor_*) and later returns the finished occurrence list; the host path below does the same with the
+    // position lists of be.sketch_haplotype.  Both end in the same `occs` / `vpool` (tests/golden/anchors.json).
+    bool dev_anchors = be.anchor_begin && be.anchor_add_haplotype && be.anchor_finish && !opt.host_anchors;
+    auto host_index = [&]() {
     // The backend calls are issued by one thread, back to back (a ctx is not thread-safe); the position -> vertex-span
     // mapping of a finished haplotype (:343-357) runs as a task on the other threads meanwhile.
 #pragma omp parallel num_threads(opt.threads)
@@ -228,6 +233,34 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             delete seg_start_p;
         }
     }
+    };
+    if (dev_anchors) {
+        if (be.anchor_begin(be.ctx, (int32_t)num_walks, (int32_t)n_vtx, top_order_map.data(), k, opt.w) != 0) {
+            err = std::string("anchor_begin failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
+        }
+        std::string hap;
+        std::vector<int64_t> seg_start;
+        std::vector<int32_t> step_vtx;
+        for (uint32_t h = 0; h < num_walks; ++h) {
+            const size_t ns = paths[h].size();
+            seg_start.assign(ns + 1, 0);
+            step_vtx.assign(paths[h].begin(), paths[h].end());
+            size_t tot = 0;
+            for (size_t i = 0; i < ns; ++i) { seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
+            seg_start[ns] = (int64_t)tot;
+            hap.clear(); hap.reserve(tot);
+            for (size_t i = 0; i < ns; ++i) hap += node_seq[paths[h][i]];
+            int64_t n = 0;
+            const double ts0 = now_s();
+            if (be.anchor_add_haplotype(be.ctx, (int32_t)h, hap.data(), (int64_t)hap.size(), step_vtx.data(), seg_start.data(), (int64_t)ns, &n) != 0) {
+                err = std::string("anchor_add_haplotype failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
+            }
+            t_sketch += now_s() - ts0;
+            sum.minimizers_per_hap[h] = n;
+        }
+    } else {
+        host_index();
+    }
     if (rc_sketch != 0) { err = err_sketch; return -1; }
     if (!opt.quiet) {
         std::cerr << "Number of Minimizers" << std::endl;              // :467-474
@@ -271,6 +304,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     const bool dbg_a = getenv("DG_DEBUG") != nullptr;
     double tla = now_s();
     auto lap_a = [&](const char *w) { if (dbg_a) { double t = now_s(); fprintf(stderr, "[dg::anchors] %-18s %.3f s\n", w, t - tla); tla = t; } };
+    auto host_join = [&]() {
     struct Raw { int32_t h; uint32_t m; };   // minimizer m of haplotype h
     std::vector<int64_t> bucket_off((size_t)count_sp_r + 1, 0);
     std::vector<std::vector<int32_t>> ids(num_walks);
@@ -460,6 +494,29 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
         }
     }
     lap_a("concatenate");
+    };
+    if (dev_anchors) {
+        dg_anchor_result ar;
+        if (be.anchor_finish(be.ctx, sp_hash.data(), (int64_t)sp_hash.size(), opt.threshold * num_walks, &ar) != 0) {
+            err = std::string("anchor_finish failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
+        }
+        lap_a("device join+filter");
+        if (ar.n_unstable_groups > 0) {
+            // a group whose order would hinge on std::sort's unstable partitioning (dg_anchor.hip): the host algorithm decides
+            if (!opt.quiet) fprintf(stderr, "[dg::anchors] %lld occurrence group(s) need the host sort; redoing the stage on the host\n", (long long)ar.n_unstable_groups);
+            dev_anchors = false;
+            host_index();
+            if (rc_sketch != 0) { err = err_sketch; return -1; }
+            host_join();
+        } else {
+            occs.resize((size_t)ar.n_occ);
+            for (int64_t i = 0; i < ar.n_occ; ++i) occs[i] = Occ{ar.occ_id[i], ar.occ_hap[i], ar.occ_off[i], ar.occ_len[i]};
+            vpool.assign(ar.vpool, ar.vpool + ar.n_vtx);
+        }
+        for (void *q : {(void *)ar.occ_id, (void *)ar.occ_hap, (void *)ar.occ_off, (void *)ar.occ_len, (void *)ar.vpool}) if (q) be.free_buf(q);
+    } else {
+        host_join();
+    }
     sum.anchors_per_hap.assign(num_walks, 0);
     for (auto &o : occs) sum.anchors_per_hap[o.h]++;
     if (!opt.quiet) {

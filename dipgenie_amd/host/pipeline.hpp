@@ -31,6 +31,11 @@ struct Backend {     // same signatures as the C ABI, plus an opaque ctx
     int (*sketch_haplotype)(void *, const char *, int64_t, int, int, uint64_t **, int64_t **, int64_t *) = nullptr;
     int (*dp_solve_diploid)(void *, const dg_dp_graph *, dg_dp_result *) = nullptr;
     void (*free_buf)(void *) = nullptr;
+    // optional: haplotype index with vertex spans + anchor join / filter / sort behind the boundary
+    int (*anchor_begin)(void *, int32_t n_haps, int32_t n_vertices, const int32_t *top_order_map, int k, int w) = nullptr;
+    int (*anchor_add_haplotype)(void *, int32_t h, const char *seq, int64_t len, const int32_t *step_vtx, const int64_t *step_start, int64_t n_steps,
+                                int64_t *n_minimizers) = nullptr;
+    int (*anchor_finish)(void *, const uint64_t *sp_hash, int64_t n_sp, float min_shared, dg_anchor_result *out) = nullptr;
     void (*hint_dp_soon)(void *, int64_t est_cells) = nullptr;   // optional, may be called repeatedly (latest wins): the DP will run later with about est_cells cells
     const char *(*last_error)() = nullptr;
 };

@@ -139,6 +139,29 @@ int dg_sketch_rank_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n_
 /* hist_dev[min(count, n_bins-1)] += 1 per entry: this range's share of Hist_kmer (solver.cpp:745-755).  Asynchronous. */
 int dg_sketch_histogram_dev(dg_ctx *, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev);
 
+/* ---- haplotype index with vertex spans + anchor join / filter / sort ----
+ * Replaces, for all haplotypes at once, Solver::index_kmers including its position -> vertex-list mapping
+ * (src/solver.cpp:277-363), Solver::compute_anchors and the Anchor_hits assembly (:415-446, 560-575), the shared-anchor
+ * filter (:590-638) and the occurrence sort (:641-663).  Call order: dg_anchor_begin, dg_anchor_add_haplotype for
+ * h = 0 .. n_haps-1, dg_sketch_reads (any time), dg_anchor_finish.  All pointers are host memory. */
+int dg_anchor_begin(dg_ctx *, int32_t n_haps, int32_t n_vertices, const int32_t *top_order_map /* [n_vertices], solver.cpp:174-199 */,
+                    int k, int w);
+/* seq = the haplotype's bases (node_seq concatenated along paths[h], :283-288); step_vtx[n_steps] = paths[h];
+ * step_start[n_steps + 1] = base offset of every step (step_start[n_steps] = len).  *n_minimizers = |index_kmers(h)|. */
+int dg_anchor_add_haplotype(dg_ctx *, int32_t h, const char *seq, int64_t len, const int32_t *step_vtx, const int64_t *step_start,
+                            int64_t n_steps, int64_t *n_minimizers);
+typedef struct dg_anchor_result {     /* Anchor_hits flattened: occurrence i = (occ_id[i], occ_hap[i], vpool[occ_off[i] .. +occ_len[i])), */
+    int64_t n_occ, n_vtx;             /* in Anchor_hits order (id asc, haplotype asc, occurrence order of :641-663)                     */
+    int32_t *occ_id, *occ_hap;        /* malloc'ed by the library: dg_free each                                                         */
+    uint32_t *occ_off, *occ_len;
+    int32_t *vpool;
+    int64_t n_candidates;             /* occurrences before the shared-anchor filter                                                    */
+    int64_t n_unstable_groups;        /* (id, haplotype) groups of > 16 occurrences holding different vertex lists with equal (front,  */
+} dg_anchor_result;                   /* back): their order would depend on std::sort's unstable partitioning -- redo the stage on the host */
+/* sp_hash[n_sp] = sorted distinct read-minimizer hashes (Sp_R keys, the output of dg_sketch_reads); min_shared =
+ * threshold * num_walks as float (:618).  Consumes the index built since dg_anchor_begin. */
+int dg_anchor_finish(dg_ctx *, const uint64_t *sp_hash, int64_t n_sp, float min_shared, dg_anchor_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -427,3 +427,35 @@ def test_dp_full_size_idempotent(gpu_ctx, built_hip, tmp_path):
     assert gpu_ctx.dp_solve(g2).value >= a.value
     g3 = capi.DpGraphArrays(4, **{n: getattr(g, n) for n in g.NAMES})
     assert gpu_ctx.dp_solve(g3).value <= a.value
+
+
+# ------------------------------------------------------------------------------------- anchors on the device
+ANCH = json.load(open(os.path.join(HERE, "golden", "anchors.json")))
+
+
+@pytest.mark.parametrize("name", [n for n, a in ANCH.items() if "same_as" not in a and not CASES[n]["reads"].startswith("<")])
+def test_device_anchor_hits_equal_reference(built_hip, gpu_ctx, name, tmp_path):
+    """dg_anchor_* (vertex spans, dictionary join, shared-anchor filter with its decimal-string key order, occurrence
+    sort) through the product CLI: the Anchor_hits + homo_bv dump must be the reference Solver object's, line by line
+    (tests/golden/anchors.json); DG_HOST_ANCHORS=1 (the host join) must give the same file"""
+    c, a = CASES[name], ANCH[name]
+    for env_extra, tag in (({}, "dev"), ({"DG_HOST_ANCHORS": "1"}, "host")):
+        dump = tmp_path / f"anchors_{tag}.txt"
+        subprocess.run([built_hip, "-t8", "-p2", f"-k{a['k']}", f"-w{a['w']}", f"-T{a['T']}", "-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]),
+                        "-o", str(tmp_path / "o.fa"), "-A", str(dump), "-X"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, **env_extra))
+        txt = open(dump).read()
+        lines = txt.splitlines()
+        if "dump" in a:
+            assert lines == a["dump"], tag
+        assert hashlib.sha256(txt.encode()).hexdigest() == a["sha256"], tag
+
+
+def test_device_anchor_hits_hg002_2x(built_hip, gpu_ctx, tmp_path):
+    """the larger read set (seeded 2x HG002 reads on MHC_4: 225,856 occurrences after the filter)"""
+    a = ANCH["mhc4_hg002_2x"]
+    gfa, reads = synth.ensure_mhc4_hg002(str(tmp_path / "hg002"))
+    dump = tmp_path / "anchors.txt"
+    subprocess.run([built_hip, "-t8", "-p2", "-g", gfa, "-r", reads, "-o", str(tmp_path / "o.fa"), "-A", str(dump), "-X"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert hashlib.sha256(open(dump, "rb").read()).hexdigest() == a["sha256"]
