@@ -18,7 +18,9 @@
 //     unstable partitioning; such groups are counted (n_unstable_groups) and the caller re-does the stage on the host
 //     (none exists in any test input or synthetic panel; identical lists tie harmlessly).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -185,12 +187,49 @@ __global__ void iota_kernel(uint32_t *p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (uint32_t)i;
 }
-// After the filter sort: head[i] = 1 where a new (id, list) run starts; a run of length >= thr drops its id (:615-622)
-__global__ void run_head_kernel(const uint32_t *__restrict__ order, int64_t n, Occs O, Lists L, uint32_t *__restrict__ head) {
+// The filter only asks how often one vertex list occurs inside an id, so equal lists are brought together by two radix
+// sorts -- by a 64-bit fingerprint of the list, then (stable) by id -- instead of a comparison sort that reads the lists.
+__device__ __forceinline__ uint64_t mix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k;
+}
+__global__ void fingerprint_kernel(Occs O, Lists L, int64_t n, uint64_t *__restrict__ fp, uint32_t *__restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t g = O.g[j], a = L.voff[g], b = L.voff[g + 1];
+    uint64_t h = mix64((uint64_t)(b - a) + 0x9E3779B97F4A7C15ULL);
+    for (uint32_t q = a; q < b; ++q) h = mix64(h ^ ((uint64_t)(uint32_t)L.v[q] + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2)));
+    fp[j] = h;
+    idx[j] = (uint32_t)j;
+}
+__global__ void gather_id_kernel(const uint32_t *__restrict__ order, const int32_t *__restrict__ oid, int64_t n, uint32_t *__restrict__ key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = (uint32_t)oid[order[i]];
+}
+__device__ __forceinline__ bool list_equal(const Lists &L, uint32_t gx, uint32_t gy) {
+    const uint32_t ax = L.voff[gx], nx = L.voff[gx + 1] - ax, ay = L.voff[gy], ny = L.voff[gy + 1] - ay;
+    if (nx != ny) return false;
+    for (uint32_t q = 0; q < nx; ++q) if (L.v[ax + q] != L.v[ay + q]) return false;
+    return true;
+}
+// head[i] = 1 where a new (id, fingerprint) run starts; inside a run every list must equal its predecessor -- a
+// fingerprint collision (different lists, same 64 bits) is counted and the caller falls back to the exact order
+__global__ void run_head_kernel(const uint32_t *__restrict__ order, int64_t n, Occs O, Lists L, const uint64_t *__restrict__ fp, uint32_t *__restrict__ head,
+                                unsigned long long *__restrict__ collisions) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool h = i == 0;
-    if (!h) { const uint32_t x = order[i - 1], y = order[i]; h = O.id[x] != O.id[y] || key_cmp(L, O.g[x], O.g[y]) != 0; }
+    if (!h) {
+        const uint32_t x = order[i - 1], y = order[i];
+        h = O.id[x] != O.id[y] || fp[x] != fp[y];
+        if (!h && !list_equal(L, O.g[x], O.g[y])) atomicAdd(collisions, 1ULL);
+    }
+    head[i] = h ? 1u : 0u;
+}
+__global__ void exact_head_kernel(const uint32_t *__restrict__ order, int64_t n, Occs O, Lists L, uint32_t *__restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool h = i == 0;
+    if (!h) { const uint32_t x = order[i - 1], y = order[i]; h = O.id[x] != O.id[y] || !list_equal(L, O.g[x], O.g[y]); }
     head[i] = h ? 1u : 0u;
 }
 __global__ void run_drop_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ head, int64_t n, Occs O, float thr, uint8_t *__restrict__ dropped) {
@@ -242,6 +281,14 @@ static int exclusive_scan_u32(DevBuf &tmp, const uint32_t *in, uint32_t *out, in
     DG_HIP(rocprim::exclusive_scan(nullptr, tb, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
     if (int rc = tmp.ensure(tb)) return rc;
     DG_HIP(rocprim::exclusive_scan(tmp.p, tb, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), s));
+    return DG_OK;
+}
+template <class K>
+static int radix_pairs(DevBuf &tmp, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t s) {
+    size_t tb = 0;
+    DG_HIP(rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, (size_t)n, 0, end_bit, s));
+    if (int rc = tmp.ensure(tb)) return rc;
+    DG_HIP(rocprim::radix_sort_pairs(tmp.p, tb, kin, kout, vin, vout, (size_t)n, 0, end_bit, s));
     return DG_OK;
 }
 template <class Cmp>
@@ -322,6 +369,16 @@ extern "C" int dg_anchor_finish(dg_ctx *c, const uint64_t *sp_hash, int64_t n_sp
     if (n_sp < 0 || (n_sp > 0 && !sp_hash) || n_sp >= ((int64_t)1 << 31)) { set_error("dg_anchor_finish: bad spectrum"); return DG_ERR_ARG; }
     memset(out, 0, sizeof *out);
     hipStream_t s = c->stream;
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    double tl = ts0.tv_sec + 1e-9 * ts0.tv_nsec;
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(s);
+        struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double t = ts.tv_sec + 1e-9 * ts.tv_nsec;
+        fprintf(stderr, "[dipgenie_hip] anchors: %-16s %.3f s\n", what, t - tl); tl = t;
+    };
     // concatenate the haplotypes: minimizer g = hap_off[h] + m, list offsets rebased
     std::vector<int64_t> hap_off(A.n_haps + 1, 0), v_off(A.n_haps + 1, 0);
     for (int h = 0; h < A.n_haps; ++h) { hap_off[h + 1] = hap_off[h] + A.haps[h]->n; v_off[h + 1] = v_off[h] + A.haps[h]->nv; }
@@ -353,6 +410,7 @@ extern "C" int dg_anchor_finish(dg_ctx *c, const uint64_t *sp_hash, int64_t n_sp
     if (int rc = d_sp.ensure(8 * (size_t)std::max<int64_t>(n_sp, 1))) return rc;
     if (n_sp) DG_HIP(hipMemcpyAsync(d_sp.p, sp_hash, 8 * (size_t)n_sp, hipMemcpyHostToDevice, s));
     DG_HIP(hipStreamSynchronize(s));
+    lap("concatenate");
     if (G == 0 || n_sp == 0) return DG_OK;
     const Lists L{d_voff.as<uint32_t>(), d_v.as<int32_t>()};
     // ---- compute_anchors (:415-446): id of every haplotype minimizer, occurrences in (haplotype, minimizer) order
@@ -375,16 +433,40 @@ extern "C" int dg_anchor_finish(dg_ctx *c, const uint64_t *sp_hash, int64_t n_sp
     hipLaunchKernelGGL(occ_scatter_kernel, dim3(blocks(G)), dim3(256), 0, s, d_id.as<int32_t>(), d_hap.as<int32_t>(), d_slot.as<uint32_t>(), G,
                        d_oid.as<int32_t>(), d_og.as<uint32_t>(), d_ohap.as<int32_t>());
     const Occs O{d_oid.as<int32_t>(), d_og.as<uint32_t>(), d_ohap.as<int32_t>()};
+    lap("join");
+    if (dbg) fprintf(stderr, "[dipgenie_hip] anchors: %lld minimizers, %u with a read hash\n", (long long)G, n_occ);
     // ---- shared-anchor filter (:590-638): equal vertex lists of one id adjacent, runs of >= min_shared drop the id
+    DevBuf d_fp, d_fp2, d_key, d_key2, d_coll;
     if (int rc = d_idx.ensure(4 * (size_t)n_occ)) return rc;
     if (int rc = d_ord.ensure(4 * (size_t)n_occ)) return rc;
     if (int rc = d_head.ensure(4 * (size_t)(n_occ + 1))) return rc;
     if (int rc = d_drop.ensure((size_t)n_sp)) return rc;
-    hipLaunchKernelGGL(iota_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_idx.as<uint32_t>(), (int64_t)n_occ);
-    if (int rc = sort_indices(d_tmp, d_idx.as<uint32_t>(), d_ord.as<uint32_t>(), n_occ, CmpFilter{O, L}, s)) return rc;
+    if (int rc = d_fp.ensure(8 * (size_t)n_occ)) return rc;
+    if (int rc = d_fp2.ensure(8 * (size_t)n_occ)) return rc;
+    if (int rc = d_key.ensure(4 * (size_t)n_occ)) return rc;
+    if (int rc = d_key2.ensure(4 * (size_t)n_occ)) return rc;
+    if (int rc = d_coll.ensure(8)) return rc;
+    DG_HIP(hipMemsetAsync(d_coll.p, 0, 8, s));
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, O, L, (int64_t)n_occ, d_fp.as<uint64_t>(), d_idx.as<uint32_t>());
+    if (int rc = radix_pairs<uint64_t>(d_tmp, d_fp.as<uint64_t>(), d_fp2.as<uint64_t>(), d_idx.as<uint32_t>(), d_ord.as<uint32_t>(), n_occ, 64, s)) return rc;
+    hipLaunchKernelGGL(gather_id_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_ord.as<uint32_t>(), d_oid.as<int32_t>(), (int64_t)n_occ, d_key.as<uint32_t>());
+    int id_bits = 1;
+    while (id_bits < 32 && ((int64_t)1 << id_bits) < n_sp) ++id_bits;
+    if (int rc = radix_pairs<uint32_t>(d_tmp, d_key.as<uint32_t>(), d_key2.as<uint32_t>(), d_ord.as<uint32_t>(), d_idx.as<uint32_t>(), n_occ, id_bits, s)) return rc;   // stable: fingerprints stay grouped
+    uint32_t *filter_order = d_idx.as<uint32_t>();
     DG_HIP(hipMemsetAsync(d_drop.p, 0, (size_t)n_sp, s));
-    hipLaunchKernelGGL(run_head_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_ord.as<uint32_t>(), (int64_t)n_occ, O, L, d_head.as<uint32_t>());
-    hipLaunchKernelGGL(run_drop_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_ord.as<uint32_t>(), d_head.as<uint32_t>(), (int64_t)n_occ, O, min_shared, d_drop.as<uint8_t>());
+    hipLaunchKernelGGL(run_head_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, filter_order, (int64_t)n_occ, O, L, d_fp.as<uint64_t>(), d_head.as<uint32_t>(),
+                       d_coll.as<unsigned long long>());
+    unsigned long long collisions = 0;
+    DG_HIP(hipMemcpyAsync(&collisions, d_coll.p, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipStreamSynchronize(s));
+    if (collisions) {                   // exact order instead (never seen: 64-bit fingerprints of <= 10^8 lists)
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_ord.as<uint32_t>(), (int64_t)n_occ);
+        if (int rc = sort_indices(d_tmp, d_ord.as<uint32_t>(), d_idx.as<uint32_t>(), n_occ, CmpFilter{O, L}, s)) return rc;
+        hipLaunchKernelGGL(exact_head_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, filter_order, (int64_t)n_occ, O, L, d_head.as<uint32_t>());
+    }
+    lap("filter sorts");
+    hipLaunchKernelGGL(run_drop_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, filter_order, d_head.as<uint32_t>(), (int64_t)n_occ, O, min_shared, d_drop.as<uint8_t>());
     // survivors, still in (haplotype, minimizer) order
     hipLaunchKernelGGL(keep_flag_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_oid.as<int32_t>(), d_drop.as<uint8_t>(), (int64_t)n_occ, d_head.as<uint32_t>());
     DG_HIP(hipMemsetAsync(d_head.as<uint32_t>() + n_occ, 0, 4, s));
@@ -396,8 +478,11 @@ extern "C" int dg_anchor_finish(dg_ctx *c, const uint64_t *sp_hash, int64_t n_sp
     if (n_keep == 0) return DG_OK;
     if (int rc = d_kept.ensure(4 * (size_t)n_keep)) return rc;
     hipLaunchKernelGGL(keep_scatter_kernel, dim3(blocks(n_occ)), dim3(256), 0, s, d_head.as<uint32_t>(), d_slot.as<uint32_t>(), (int64_t)n_occ, d_kept.as<uint32_t>());
+    lap("drop + compact");
+    if (dbg) fprintf(stderr, "[dipgenie_hip] anchors: %u occurrences survive the filter\n", n_keep);
     // ---- occurrence sort (:641-663) in Anchor_hits order
     if (int rc = sort_indices(d_tmp, d_kept.as<uint32_t>(), d_ord.as<uint32_t>(), n_keep, CmpFinal{O, L}, s)) return rc;
+    lap("final sort");
     if (int rc = d_out_id.ensure(4 * (size_t)n_keep)) return rc;
     if (int rc = d_out_hap.ensure(4 * (size_t)n_keep)) return rc;
     if (int rc = d_out_len.ensure(4 * (size_t)(n_keep + 1))) return rc;
@@ -426,6 +511,7 @@ extern "C" int dg_anchor_finish(dg_ctx *c, const uint64_t *sp_hash, int64_t n_sp
     DG_HIP(hipMemcpyAsync(out->occ_len, d_out_len.p, 4 * (size_t)n_keep, hipMemcpyDeviceToHost, s));
     if (n_vtx) DG_HIP(hipMemcpyAsync(out->vpool, d_vpool.p, 4 * (size_t)n_vtx, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
+    lap("emit + download");
     out->n_occ = n_keep; out->n_vtx = n_vtx; out->n_candidates = n_occ; out->n_unstable_groups = (int64_t)unstable;
     delete c->an;                       // the index is consumed
     c->an = nullptr;

@@ -293,14 +293,19 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
 
     // ---- compute_anchors (solver.cpp:415-446, 560-575): hap minimizers whose hash is in Sp_R ----
     t0 = now_s();
-    if (opt.ploidy == 2 && be.hint_dp_soon) {       // device work of the sketches is done: let the device side reserve the DP lattice
+    // Once the device work of this stage is done the device side may reserve the DP lattice: mapping 100+ GB takes
+    // seconds during which every other HIP call of the process queues behind the allocation, so it must start where
+    // only host work follows -- before the host join, after the device join.
+    auto hint_lattice = [&]() {
+        if (!(opt.ploidy == 2 && be.hint_dp_soon)) return;
         size_t max_path = 0;
         for (auto &pw : paths) max_path = std::max(max_path, pw.size());
         // Generous on purpose (levels ~ 2.5 x path steps, width ~ 5 x walks: chain + recombination + dummy vertices):
         // reserving too much costs nothing once the exact figure (diploid(), below) stops it, too little stalls the DP.
         const double kk = 5.0 * (double)num_walks;
         be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, 2.5 * (double)max_path * kk * kk * (opt.R + 1)));
-    }
+    };
+    if (!dev_anchors) hint_lattice();
     const bool dbg_a = getenv("DG_DEBUG") != nullptr;
     double tla = now_s();
     auto lap_a = [&](const char *w) { if (dbg_a) { double t = now_s(); fprintf(stderr, "[dg::anchors] %-18s %.3f s\n", w, t - tla); tla = t; } };
@@ -501,6 +506,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             err = std::string("anchor_finish failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
         }
         lap_a("device join+filter");
+        hint_lattice();
         if (ar.n_unstable_groups > 0) {
             // a group whose order would hinge on std::sort's unstable partitioning (dg_anchor.hip): the host algorithm decides
             if (!opt.quiet) fprintf(stderr, "[dg::anchors] %lld occurrence group(s) need the host sort; redoing the stage on the host\n", (long long)ar.n_unstable_groups);
