@@ -51,7 +51,7 @@ SYMBOLS = [
     "dg_dp_set_option", "dg_dp_get_launch_profile", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
-    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish",
+    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -86,6 +86,13 @@ lib.dg_sketch_merge_runs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c
 lib.dg_sketch_partition_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 lib.dg_sketch_rank_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
 lib.dg_sketch_histogram_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+
+
+class HapGraph(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("R", C.c_int32), ("out_off", C.c_void_p), ("out_dst", C.c_void_p), ("out_w", C.c_void_p), ("n_colours", C.c_void_p)]
+
+
+lib.dg_dp_solve_haploid.argtypes = [C.c_void_p, C.POINTER(HapGraph), C.c_void_p, C.c_void_p, C.c_void_p]
 
 
 class AnchorResult(C.Structure):
@@ -230,6 +237,16 @@ class Context:
     def dp_solve(self, g):
         self.dp_load_graph(g)
         return self.dp_run()
+
+    def dp_solve_haploid(self, R, out_off, out_dst, out_w, n_colours):
+        """haploid (vertex, r) DP: returns dp, back_vtx, back_r as [n, R+1] int32 arrays"""
+        out_off = np.ascontiguousarray(out_off, np.int64); out_dst = np.ascontiguousarray(out_dst, np.int32)
+        out_w = np.ascontiguousarray(out_w, np.uint8); n_colours = np.ascontiguousarray(n_colours, np.int32)
+        n = out_off.size - 1
+        g = HapGraph(n, R, out_off.ctypes.data, out_dst.ctypes.data if out_dst.size else 0, out_w.ctypes.data if out_w.size else 0, n_colours.ctypes.data)
+        arrs = [np.zeros((n, R + 1), np.int32) for _ in range(3)]
+        _check(lib.dg_dp_solve_haploid(self.h, C.byref(g), *(a.ctypes.data for a in arrs)), "dg_dp_solve_haploid")
+        return arrs
 
     def dp_timing(self):
         t = DpTiming()

@@ -53,6 +53,10 @@ static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) {
     dg_ctx *x = ((LazyCtx *)c)->get();
     return x ? dg_dp_solve_diploid(x, g, r) : DG_ERR_NO_DEVICE;
 }
+static int b_hap(void *c, const dg_hap_graph *g, int32_t *dp, int32_t *bv, int32_t *br) {
+    dg_ctx *x = ((LazyCtx *)c)->get();
+    return x ? dg_dp_solve_haploid(x, g, dp, bv, br) : DG_ERR_NO_DEVICE;
+}
 static int b_anchor_begin(void *c, int32_t nh, int32_t nv, const int32_t *top, int k, int w) {
     dg_ctx *x = ((LazyCtx *)c)->get();
     return x ? dg_anchor_begin(x, nh, nv, top, k, w) : DG_ERR_NO_DEVICE;
@@ -132,6 +136,8 @@ int main(int argc, char **argv) {
     p.be.dp_solve_diploid = b_dp;
     p.be.free_buf = dg_free;
     p.be.hint_dp_soon = b_hint;
+    p.be.dp_solve_haploid = b_hap;
+    if (getenv("DG_HOST_HAPLOID")) p.opt.host_haploid = true;   // A/B and parity runs: the host gather loop
     p.be.anchor_begin = b_anchor_begin;
     p.be.anchor_add_haplotype = b_anchor_add;
     p.be.anchor_finish = b_anchor_finish;

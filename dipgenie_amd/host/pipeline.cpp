@@ -802,82 +802,132 @@ bool DpGraphStorage::load(const std::string &path, int &R) {
 // ======================================================================================
 // haploid DP  (approximator.cpp:44-168) -- CPU by design
 // ======================================================================================
-std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R) {
-    double th0 = now_s();
-    int n = g.n;
-    const std::size_t N = (std::size_t)n * (R + 1);
-    std::vector<int> dp(N, 0), back_vtx(N, -1), back_r(N, -1);         // :50-52 (0, not -inf: quirk kept)
-    auto idx = [&](int v, int r) -> std::size_t { return std::size_t(v) * (R + 1) + r; };
-    for (int u = 0; u < n; u++)
-        for (int r = 0; r <= R; r++)
-            for (int64_t e = g.adj_off[u]; e < g.adj_off[u + 1]; ++e) {
-                const int v = g.adj_dst[e], w_uv = g.adj_w[e];
-                const std::size_t csz = (std::size_t)g.ncol(v);
-                // NB the reference compares in size_t (int + size_t > int): :60
-                if (r + w_uv <= R && (std::size_t)dp[idx(u, r)] + csz > (std::size_t)dp[idx(v, r + w_uv)]) {
-                    dp[idx(v, r + w_uv)] = dp[idx(u, r)] + (int)csz;
-                    back_vtx[idx(v, r + w_uv)] = u;
-                    back_r[idx(v, r + w_uv)] = r;
-                }
+// Haploid (vertex, r) tables of approximator.cpp:44-72 in gather form (the host twin of dg_dp_solve_haploid): vertices are
+// in topological order, so dp[u][.] is final before any successor of u is visited and
+//   dp[v][r2] = max(0, max over in-edges (u, w) of dp[u][r2 - w] + |color[v]|).
+// The reference's scatter loop only replaces on a strictly larger value (:60), i.e. the first candidate in its visiting
+// order (u ascending, source r ascending = weight-1 edge before weight-0 edge of the same u, adjacency order) keeps a
+// tie; the in-edge lists below are built in exactly that order.  Every state starts at 0 with back pointers -1 (:50-52).
+namespace {
+struct HapTables {
+    int RP = 0;
+    std::vector<int32_t> dp, back_vtx, back_r;                         // [v * RP + r]
+    size_t at(int v, int r) const { return (size_t)v * RP + r; }
+};
+
+void haploid_tables_host(const ExpandedGraph &g, int R, HapTables &T) {
+    const int n = g.n, RP = R + 1;
+    std::vector<int64_t> in_off((size_t)n + 1, 0);
+    for (int64_t e = 0; e < g.adj_off[n]; ++e) in_off[g.adj_dst[e] + 1]++;
+    for (int v = 0; v < n; ++v) in_off[v + 1] += in_off[v];
+    std::vector<uint32_t> in_src((size_t)g.adj_off[n]);                // source | weight << 31
+    {
+        std::vector<int64_t> fill(in_off.begin(), in_off.end() - 1);
+        for (int u = 0; u < n; ++u)
+            for (int64_t e = g.adj_off[u]; e < g.adj_off[u + 1]; ++e) in_src[fill[g.adj_dst[e]]++] = (uint32_t)u | ((uint32_t)g.adj_w[e] << 31);
+    }
+    for (int v = 0; v < n; ++v) {                                      // a source's weight-1 edges first, stably
+        uint32_t *a = in_src.data() + in_off[v];
+        const int64_t d = in_off[v + 1] - in_off[v];
+        for (int64_t i = 0; i < d;) {
+            int64_t j = i;
+            while (j < d && (a[j] & 0x7FFFFFFFu) == (a[i] & 0x7FFFFFFFu)) ++j;
+            if (j - i > 1) std::stable_partition(a + i, a + j, [](uint32_t x) { return (x >> 31) != 0; });
+            i = j;
+        }
+    }
+    T.RP = RP;
+    T.dp.assign((size_t)n * RP, 0); T.back_vtx.assign((size_t)n * RP, -1); T.back_r.assign((size_t)n * RP, -1);
+    for (int v = 0; v < n; ++v) {
+        const int gain = (int)g.ncol(v);
+        for (int r2 = 0; r2 <= R; ++r2) {
+            int best = 0, from = -1, from_r = -1;
+            for (int64_t e = in_off[v]; e < in_off[v + 1]; ++e) {
+                const int u = (int)(in_src[e] & 0x7FFFFFFFu), r = r2 - (int)(in_src[e] >> 31);
+                if (r < 0) continue;
+                const int cand = T.dp[T.at(u, r)] + gain;
+                if (cand > best) { best = cand; from = u; from_r = r; }
             }
+            T.dp[T.at(v, r2)] = best; T.back_vtx[T.at(v, r2)] = from; T.back_r[T.at(v, r2)] = from_r;
+        }
+    }
+}
+
+// visits the vertices of the path that ends in (sink, r), sink first (:83-101, :141-153)
+template <class F> void walk_back(const HapTables &T, int sink, int r, F &&visit) {
+    for (int v = sink; v != -1;) {
+        visit(v);
+        const size_t o = T.at(v, r);
+        v = T.back_vtx[o];
+        r = T.back_r[o];
+    }
+}
+}  // namespace
+
+std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R, std::string &err) {
     const bool dbg_h = getenv("DG_DEBUG") != nullptr;
-    if (dbg_h) fprintf(stderr, "[dg::haploid] scatter DP %.3f s\n", now_s() - th0);
+    double th0 = now_s();
+    const int n = g.n;
+    HapTables T;
+    if (be.dp_solve_haploid && !opt.host_haploid) {                    // the device loop
+        std::vector<int32_t> ncol(n);
+        for (int v = 0; v < n; ++v) ncol[v] = (int32_t)g.ncol(v);
+        dg_hap_graph hg{n, R, g.adj_off.data(), g.adj_dst.data(), g.adj_w.data(), ncol.data()};
+        T.RP = R + 1;
+        T.dp.resize((size_t)n * T.RP); T.back_vtx.resize(T.dp.size()); T.back_r.resize(T.dp.size());
+        if (be.dp_solve_haploid(be.ctx, &hg, T.dp.data(), T.back_vtx.data(), T.back_r.data()) != 0) {
+            err = std::string("dp_solve_haploid failed: ") + (be.last_error ? be.last_error() : "?");
+            return {};
+        }
+    } else {
+        haploid_tables_host(g, R, T);
+    }
+    if (dbg_h) fprintf(stderr, "[dg::haploid] (vertex, r) tables %.3f s\n", now_s() - th0);
     th0 = now_s();
-    // :74-113.  The reference fills an unordered_set and a std::map per r; only the number of distinct colours on the
-    // path and (for the certificate line) the mean occurrence count are used: flat counters per r, the R+1 walks in parallel.
+    // :74-113.  Per recombination count: number of distinct colours on its path, and (certificate line) their mean
+    // occurrence count.  The reference fills an unordered_set and a std::map per r; flat counters do, the R + 1 walks
+    // run in parallel.
     int32_t max_col = -1;
     for (int32_t c : g.col_pool) max_col = std::max(max_col, c);
     std::vector<int> colors_by_r(R + 1, 0);
     std::vector<float> avg_by_r(R + 1, 0.f);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(opt.threads > 0 ? opt.threads : 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(opt.threads)
     for (int r = 0; r <= R; r++) {
         std::vector<int32_t> cnt((size_t)max_col + 1, 0);
-        int cur_vtx = n - 1, cur_r = r, distinct = 0;
-        while (cur_vtx != -1) {
-            for (int64_t q = g.col_off[cur_vtx]; q < g.col_off[cur_vtx + 1]; ++q) distinct += (cnt[g.col_pool[q]]++ == 0);
-            int temp_vtx = cur_vtx;
-            cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
-            cur_r = back_r[idx(temp_vtx, cur_r)];
-        }
+        int distinct = 0;
+        walk_back(T, n - 1, r, [&](int v) { for (int64_t q = g.col_off[v]; q < g.col_off[v + 1]; ++q) distinct += (cnt[g.col_pool[q]]++ == 0); });
         colors_by_r[r] = distinct;
-        float avg = 0;                                                 // :106-111: float sum in ascending colour order
-        for (int32_t c = 0; c <= max_col; ++c) if (cnt[c]) avg += cnt[c];
-        avg_by_r[r] = avg / distinct;                                  // 0/0 -> nan, as the reference prints it
+        float total = 0;                                               // :106-111: float sum in ascending colour order
+        for (int32_t c = 0; c <= max_col; ++c) if (cnt[c]) total += cnt[c];
+        avg_by_r[r] = total / distinct;                                // 0/0 -> nan, as the reference prints it
     }
     if (dbg_h) fprintf(stderr, "[dg::haploid] per-r backtracks %.3f s\n", now_s() - th0);
     if (!opt.quiet)
         for (int i = 0; i < R; ++i) std::cout << "Approximation ratio certificate: " << avg_by_r[i] << std::endl;
-    int best_r = 0;                                                    // :116-136
-    double max_delta = 0;
-    for (size_t i = 0; i + 1 < colors_by_r.size(); ++i) {
-        if (!opt.quiet) std::cout << "r: " << i << " true score: " << colors_by_r[i] << std::endl;
-        int delta = colors_by_r[i + 1] - colors_by_r[i];
-        if (std::abs(delta) > max_delta) max_delta = std::abs(delta);
+    // :116-136  the first r whose gain in distinct colours, as an angle against the largest gain, falls below 5 degrees
+    // (double arithmetic; a 0/0 slope is NaN, compares false and falls through to r = 0 like the reference)
+    double steepest = 0;
+    for (int r = 0; r < R; ++r) {
+        if (!opt.quiet) std::cout << "r: " << r << " true score: " << colors_by_r[r] << std::endl;
+        steepest = std::max(steepest, (double)std::abs(colors_by_r[r + 1] - colors_by_r[r]));
     }
-    for (size_t r = 0; r + 1 < colors_by_r.size(); ++r) {
-        int delta = colors_by_r[r + 1] - colors_by_r[r];
-        double angle_rad = std::atan(static_cast<double>(delta) / max_delta);
-        double angle_deg = angle_rad * 180.0 / M_PI;
+    int best_r = 0;
+    for (int r = 0; r < R; ++r) {
+        const int gain = colors_by_r[r + 1] - colors_by_r[r];
+        const double deg = std::atan(static_cast<double>(gain) / steepest) * 180.0 / M_PI;
         if (!opt.quiet)
-            std::cout << "r: " << r << " -> " << r + 1 << ", \xCE\x94" "colors: " << delta << ", angle: " << angle_deg << "\xC2\xB0" << std::endl;
-        if (angle_deg < 5 /*HAP_ANGLE_THRESHOLD*/) { best_r = (int)r; break; }
+            std::cout << "r: " << r << " -> " << r + 1 << ", \xCE\x94" "colors: " << gain << ", angle: " << deg << "\xC2\xB0" << std::endl;
+        if (deg < 5 /* HAP_ANGLE_THRESHOLD */) { best_r = r; break; }
     }
     if (!opt.quiet) std::cerr << "Recombination count: " << best_r << std::endl;
     sum.best_r_haploid = best_r;
     std::vector<int> path;                                             // :141-153
-    int cur_vtx = n - 1, cur_r = best_r;
-    while (cur_vtx != -1) {
-        path.push_back(cur_vtx);
-        int temp_vtx = cur_vtx;
-        cur_vtx = back_vtx[idx(cur_vtx, cur_r)];
-        cur_r = back_r[idx(temp_vtx, cur_r)];
-    }
-    std::reverse(path.begin(), path.end());
-    std::vector<int> out;
-    std::unordered_set<int> seen;                                      // remove_duplicates (:30-40)
-    for (auto u : path)
-        for (uint32_t q = 0; q < g.orig_len[u]; ++q) {
-            const int uo = g.orig_pool[g.orig_off[u] + q];
+    walk_back(T, n - 1, best_r, [&](int v) { path.push_back(v); });
+    std::vector<int> out;                                              // original vertices, source to sink, first occurrence only (:30-40)
+    std::unordered_set<int> seen;
+    for (auto it = path.rbegin(); it != path.rend(); ++it)
+        for (uint32_t q = 0; q < g.orig_len[*it]; ++q) {
+            const int uo = g.orig_pool[g.orig_off[*it] + q];
             if (seen.insert(uo).second) out.push_back(uo);
         }
     return out;
@@ -1089,7 +1139,8 @@ int Pipeline::solve(std::string &err) {
 
     if (opt.ploidy == 1) {                                             // :1260-1278
         t0 = now_s();
-        std::vector<int> dp_path = haploid_dp(g, opt.R);
+        std::vector<int> dp_path = haploid_dp(g, opt.R, err);
+        if (!err.empty()) return -1;
         std::string out;
         for (auto u : dp_path) out += node_seq[u];
         std::ofstream f(opt.hap_file, std::ios::out);

@@ -30,6 +30,7 @@ struct Backend {     // same signatures as the C ABI, plus an opaque ctx
     int (*sketch_reads)(void *, const char *, const int64_t *, int64_t, int, int, uint64_t **, int32_t **, int64_t *) = nullptr;
     int (*sketch_haplotype)(void *, const char *, int64_t, int, int, uint64_t **, int64_t **, int64_t *) = nullptr;
     int (*dp_solve_diploid)(void *, const dg_dp_graph *, dg_dp_result *) = nullptr;
+    int (*dp_solve_haploid)(void *, const dg_hap_graph *, int32_t *dp, int32_t *back_vtx, int32_t *back_r) = nullptr;   // optional
     void (*free_buf)(void *) = nullptr;
     // optional: haplotype index with vertex spans + anchor join / filter / sort behind the boundary
     int (*anchor_begin)(void *, int32_t n_haps, int32_t n_vertices, const int32_t *top_order_map, int k, int w) = nullptr;
@@ -52,6 +53,7 @@ struct Options {
     std::string dump_prefix;  // (ours) if set, dump the levelized DP graph to <prefix>.dpg
     bool dump_only = false;   // (ours, tests) stop after the dump
     std::string anchor_dump;  // (ours, tests) if set, write Anchor_hits + homo_bv as text (format of oracle/ref_harness.cpp `anchors`)
+    bool host_haploid = false;   // (ours, tests) keep the haploid (vertex, r) tables on the host even if the backend offers them
     bool host_anchors = false;   // (ours, tests) keep the anchor join / filter / sort on the host even if the backend offers it
 };
 
@@ -162,7 +164,7 @@ class Pipeline {
 
   private:
     void read_gfa_from(const GfaGraph &g);
-    std::vector<int> haploid_dp(const ExpandedGraph &g, int R);
+    std::vector<int> haploid_dp(const ExpandedGraph &g, int R, std::string &err);
     int diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
                 const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err);
     void stamp(const char *name, double t0);

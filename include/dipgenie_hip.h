@@ -6,6 +6,10 @@
  *   dg_dp_solve_diploid     replaces the level loop + sink read-out of
  *                           Approximator::diploid_dp_approximation_solver
  *                           (src/approximator.h:26, src/approximator.cpp:532-716 and :757-785)
+ *   dg_dp_solve_haploid     replaces the scatter loop of Approximator::dp_approximation_solver
+ *                           (src/approximator.h:25, src/approximator.cpp:44-72)
+ *   dg_anchor_*             replace the vertex-span mapping of Solver::index_kmers, Solver::compute_anchors, the
+ *                           shared-anchor filter and the occurrence sort (src/solver.cpp:343-357, 415-446, 560-663)
  *   dg_sketch_reads         replaces the per-read Solver::compute_hashes loop and the Sp_R /
  *                           kmer_count maps (src/solver.h:101, src/solver.cpp:526-546, 711-732)
  *   dg_sketch_haplotype     replaces the window loop of Solver::index_kmers
@@ -91,6 +95,19 @@ int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
 /* measurement: which sweep kernel variants the last dg_dp_run launched, as "name:count name:count ..." (the names
  * rocprofv3 reports, abbreviated); lets a profile taken in another process be matched against this run. */
 int dg_dp_get_launch_profile(dg_ctx *, char *buf, int cap);
+
+/* ---- haploid (vertex, r) DP ---- */
+typedef struct dg_hap_graph {         /* expanded graph after topologically_reorder: every edge u -> v has u < v */
+    int32_t n_vertices, R;
+    const int64_t *out_off;           /* [n_vertices+1] out-CSR, adjacency order preserved */
+    const int32_t *out_dst;
+    const uint8_t *out_w;             /* recombination weight 0/1 */
+    const int32_t *n_colours;         /* |color[v]| */
+} dg_hap_graph;
+/* replaces the scatter loop of Approximator::dp_approximation_solver (src/approximator.cpp:44-72): fills the caller's
+ * dp / back_vtx / back_r arrays, each [n_vertices * (R+1)], index v * (R+1) + r; the per-r backtracks and the choice of
+ * best_r (:74-153, double arithmetic) stay with the caller.  Synchronises. */
+int dg_dp_solve_haploid(dg_ctx *, const dg_hap_graph *, int32_t *dp, int32_t *back_vtx, int32_t *back_r);
 
 /* ---- (w,k)-minimizer sketching ---- */
 /* reads: concatenated bases + offsets [n_reads+1] (host). Outputs (malloc'ed by the library, release

@@ -67,6 +67,18 @@ typedef struct orc_dp_result {
  * i.e. it pins the value AND the winning predecessor (tie-break :657-659) of every cell. */
 int      orc_dp_solve_diploid(const orc_dp_graph *g, orc_dp_result *res, uint64_t *level_digest);
 
+/* ---- haploid DP (src/approximator.cpp:44-72) ---- */
+typedef struct orc_hap_graph {      /* expanded graph after topologically_reorder: every edge u -> v has u < v */
+    int32_t n_vertices, R;
+    const int64_t *out_off;         /* [n_vertices+1], adjacency order preserved */
+    const int32_t *out_dst;
+    const uint8_t *out_w;           /* 0/1 */
+    const int32_t *n_colours;       /* |color[v]| */
+} orc_hap_graph;
+/* Literal restatement of the scatter loop :47-72: dp, back_vtx, back_r as [v * (R+1) + r]; every state starts at 0 with
+ * back pointers -1 (:50-52), updates are strict (>), so the FIRST candidate in (u asc, r asc, adjacency order) wins. */
+int      orc_dp_haploid(const orc_hap_graph *g, int32_t *dp, int32_t *back_vtx, int32_t *back_r);
+
 /* inter_size_union2x2 / symdiff_size_union2x2 (approximator.cpp:269-311) on sorted int lists */
 int      orc_inter_union2x2(const int32_t *A, int na, const int32_t *B, int nb,
                             const int32_t *C, int nc, const int32_t *D, int nd);

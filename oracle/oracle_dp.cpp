@@ -221,3 +221,22 @@ extern "C" int orc_dp_solve_diploid(const orc_dp_graph *g, orc_dp_result *res, u
     res->n_p2 = materialize(pool2, sink.p2_tail, res->p2_from, res->p2_to);
     return 0;
 }
+
+extern "C" int orc_dp_haploid(const orc_hap_graph *g, int32_t *dp, int32_t *back_vtx, int32_t *back_r) {   // :44-72
+    const int n = g->n_vertices, R = g->R;
+    const size_t N = (size_t)n * (R + 1);
+    for (size_t t = 0; t < N; ++t) { dp[t] = 0; back_vtx[t] = -1; back_r[t] = -1; }                       // :50-52
+    auto idx = [&](int v, int r) { return (size_t)v * (R + 1) + r; };
+    for (int u = 0; u < n; ++u)                                                                            // :55
+        for (int r = 0; r <= R; ++r)
+            for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) {
+                const int v = g->out_dst[e], w = g->out_w[e];
+                // :60 -- the reference compares in size_t (int + size_t > int); every value is >= 0, so int compares equal
+                if (r + w <= R && (size_t)dp[idx(u, r)] + (size_t)g->n_colours[v] > (size_t)dp[idx(v, r + w)]) {
+                    dp[idx(v, r + w)] = dp[idx(u, r)] + g->n_colours[v];
+                    back_vtx[idx(v, r + w)] = u;
+                    back_r[idx(v, r + w)] = r;
+                }
+            }
+    return 0;
+}

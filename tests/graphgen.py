@@ -53,3 +53,25 @@ def random_levelized(seed, n_levels=12, max_width=9, R=3, p_w1=0.3, p_colour=0.4
     return DpGraphArrays(R, level_off=level_off, out_off=out_off, out_dst=out_dst, out_w=out_w,
                          hom_off=hom_off, hom_col=np.array([c for x in hom for c in x], np.int32),
                          het_off=het_off, het_col=np.array([c for x in het for c in x], np.int32))
+
+
+def random_topological(seed, n=60, R=4, avg_deg=2.0, p_w1=0.4, p_zero_colour=0.5, max_colours=4, span=8, dup=0.15):
+    """A DAG whose vertex ids are a topological order (every edge u -> v has u < v), as ExpandedGraph::topologically_reorder
+    leaves it for the haploid DP: edges reach up to `span` ids ahead (several depth levels), parallel edges may carry
+    DIFFERENT weights (the scatter loop's arrival order then matters), many vertices carry no colour (ties at value 0).
+    Returns (out_off, out_dst, out_w, n_colours)."""
+    rng = np.random.default_rng(seed)
+    out = [[] for _ in range(n)]
+    for u in range(n - 1):
+        for _ in range(1 + int(rng.poisson(avg_deg - 1))):
+            v = int(min(n - 1, u + 1 + rng.integers(0, span)))
+            w = int(rng.random() < p_w1)
+            out[u].append((v, w))
+            if rng.random() < dup:
+                out[u].append((v, int(rng.random() < 0.5)))      # parallel edge, independent weight
+    out_off = np.zeros(n + 1, np.int64)
+    out_off[1:] = np.cumsum([len(o) for o in out])
+    out_dst = np.array([v for o in out for (v, _) in o], np.int32)
+    out_w = np.array([w for o in out for (_, w) in o], np.uint8)
+    ncol = np.where(rng.random(n) < p_zero_colour, 0, rng.integers(1, max_colours + 1, n)).astype(np.int32)
+    return out_off, out_dst, out_w, ncol

@@ -50,6 +50,25 @@ lib.orc_inter_union2x2.argtypes = [C.c_void_p, C.c_int] * 4
 lib.orc_symdiff_union2x2.argtypes = [C.c_void_p, C.c_int] * 4
 
 
+class OrcHapGraph(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("R", C.c_int32), ("out_off", C.c_void_p), ("out_dst", C.c_void_p), ("out_w", C.c_void_p),
+                ("n_colours", C.c_void_p)]
+
+
+lib.orc_dp_haploid.argtypes = [C.POINTER(OrcHapGraph), C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def dp_haploid(R, out_off, out_dst, out_w, n_colours):
+    """literal scatter DP (approximator.cpp:44-72): returns dp, back_vtx, back_r as [n, R+1] int32 arrays"""
+    out_off = np.ascontiguousarray(out_off, np.int64); out_dst = np.ascontiguousarray(out_dst, np.int32)
+    out_w = np.ascontiguousarray(out_w, np.uint8); n_colours = np.ascontiguousarray(n_colours, np.int32)
+    n = out_off.size - 1
+    g = OrcHapGraph(n, R, out_off.ctypes.data, out_dst.ctypes.data if out_dst.size else 0, out_w.ctypes.data if out_w.size else 0, n_colours.ctypes.data)
+    arrs = [np.zeros((n, R + 1), np.int32) for _ in range(3)]
+    assert lib.orc_dp_haploid(C.byref(g), *(a.ctypes.data for a in arrs)) == 0
+    return arrs
+
+
 def hash_kmer(s: bytes) -> int:
     return lib.orc_hash_kmer(s, len(s))
 

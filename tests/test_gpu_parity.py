@@ -459,3 +459,37 @@ def test_device_anchor_hits_hg002_2x(built_hip, gpu_ctx, tmp_path):
     subprocess.run([built_hip, "-t8", "-p2", "-g", gfa, "-r", reads, "-o", str(tmp_path / "o.fa"), "-A", str(dump), "-X"], check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert hashlib.sha256(open(dump, "rb").read()).hexdigest() == a["sha256"]
+
+
+# ------------------------------------------------------------------------------------- haploid DP on the device
+@pytest.mark.parametrize("seed", range(12))
+def test_haploid_dp_vs_oracle(gpu_ctx, seed):
+    """dg_dp_solve_haploid against the literal scatter loop (approximator.cpp:44-72): every dp / back_vtx / back_r entry"""
+    kw = [dict(), dict(n=400, R=18, span=20), dict(n=50, R=0), dict(n=300, R=6, p_zero_colour=1.0), dict(n=300, R=6, p_zero_colour=0.0, dup=0.5),
+          dict(n=2000, R=3, span=2, avg_deg=1.2), dict(n=1, R=2), dict(n=2, R=1), dict(n=500, R=70, span=40, avg_deg=4.0),
+          dict(n=800, R=18, p_w1=1.0), dict(n=800, R=18, p_w1=0.0), dict(n=5000, R=18, span=3)][seed]
+    off, dst, w, ncol = graphgen.random_topological(9100 + seed, **kw)
+    R = kw.get("R", 4)
+    got = gpu_ctx.dp_solve_haploid(R, off, dst, w, ncol)
+    want = orc.dp_haploid(R, off, dst, w, ncol)
+    for name, a, b in zip(("dp", "back_vtx", "back_r"), got, want):
+        assert np.array_equal(a, b), (name, seed)
+
+
+def test_haploid_rejects_unordered_graph(gpu_ctx):
+    off, dst, w, ncol = graphgen.random_topological(1, n=10)
+    dst = dst.copy(); dst[0] = 0                                 # edge back to vertex 0
+    with pytest.raises(capi.DgError, match="topological"):
+        gpu_ctx.dp_solve_haploid(2, off, dst, w, ncol)
+
+
+@pytest.mark.parametrize("name", ["toy2_p1", "toy1_p1", "bub_a_p1", "bub_c_p1"])
+def test_cli_haploid_device_equals_host_tables(built_hip, gpu_ctx, name, tmp_path):
+    """-p1 through the device (vertex, r) tables and through the host gather loop (DG_HOST_HAPLOID=1): same FASTA = the
+    reference's (tests/golden/e2e.json)"""
+    c = CASES[name]
+    for env_extra in ({}, {"DG_HOST_HAPLOID": "1"}):
+        out = tmp_path / "o.fa"
+        subprocess.run([built_hip, "-t4"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, **env_extra))
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["fasta_md5"]
