@@ -10,7 +10,7 @@
 // strict '>' makes the FIRST candidate of the scatter order win: in-edges are stored sorted by (u asc, w desc -- the
 // smaller source r comes first --, adjacency order asc) and a candidate replaces the running best only if strictly larger.
 //
-// Level-synchronous: vertices are renumbered by longest-path depth (ties by id); one persistent workgroup walks the
+// Level-synchronous: vertices are listed by longest-path depth (ties by id); one persistent workgroup walks the
 // levels with a barrier in between (a level holds a handful of vertices: a launch per level would cost ~3 us x 10^5-10^6
 // levels; the barrier costs ~1 us).  One wave per vertex, lanes over r.  Low value by SURVEY.md s8f-4 (the host scatter
 // loop takes 0.05-0.12 s on MHC_4); it exists so that -p1 runs its DP behind the same boundary as -p2.
@@ -21,12 +21,11 @@
 
 namespace dgi {
 
-struct HapVertex { uint32_t e0, deg; int32_t ncol, old_id; };     // in-edge slice of the renumbered vertex
+struct HapVertex { uint32_t e0, deg; int32_t ncol, id; };         // a vertex in level order: its in-edge slice, |color|, id
 
 __global__ __launch_bounds__(1024) void hap_dp_kernel(const uint32_t *__restrict__ level_off, int n_levels, const HapVertex *__restrict__ vtx,
-                                                      const uint32_t *__restrict__ in_src /* renumbered source | w << 31 */, int RP,
-                                                      int32_t *__restrict__ dp, int32_t *__restrict__ back_vtx, int32_t *__restrict__ back_r,
-                                                      const int32_t *__restrict__ old_of_new) {
+                                                      const uint32_t *__restrict__ in_src /* source | w << 31 */, int RP,
+                                                      int32_t *__restrict__ dp, int32_t *__restrict__ back_vtx, int32_t *__restrict__ back_r) {
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), n_waves = (int)(blockDim.x >> 6);
     for (int l = 0; l < n_levels; ++l) {
         const uint32_t a = level_off[l], b = level_off[l + 1];
@@ -39,10 +38,10 @@ __global__ __launch_bounds__(1024) void hap_dp_kernel(const uint32_t *__restrict
                     const int u = (int)(s & 0x7FFFFFFFu), r = r2 - (int)(s >> 31);
                     if (r >= 0) {                                           // :60  r + w <= R
                         const int cand = dp[(size_t)u * RP + r] + hv.ncol;
-                        if (cand > best) { best = cand; bu = old_of_new[u]; br = r; }   // strict: first arrival keeps ties
+                        if (cand > best) { best = cand; bu = u; br = r; }   // strict: first arrival keeps ties
                     }
                 }
-                const size_t o = (size_t)v * RP + r2;
+                const size_t o = (size_t)hv.id * RP + r2;
                 dp[o] = best; back_vtx[o] = bu; back_r[o] = br;
             }
         }
@@ -78,23 +77,21 @@ extern "C" int dg_dp_solve_haploid(dg_ctx *c, const dg_hap_graph *g, int32_t *dp
     std::vector<uint32_t> level_off((size_t)L + 1, 0);
     for (int v = 0; v < n; ++v) level_off[depth[v] + 1]++;
     for (int l = 0; l < L; ++l) level_off[l + 1] += level_off[l];
-    std::vector<int32_t> new_of_old(n), old_of_new(n);
+    // vertices in level order with their in-edges in scatter arrival order: (u asc, w desc, adjacency order asc)
+    std::vector<int32_t> slot_of(n);
+    std::vector<HapVertex> vtx(n);
     {
         std::vector<uint32_t> fill(level_off.begin(), level_off.end() - 1);
-        for (int v = 0; v < n; ++v) { const uint32_t q = fill[depth[v]]++; new_of_old[v] = (int32_t)q; old_of_new[q] = v; }
+        for (int v = 0; v < n; ++v) { const uint32_t q = fill[depth[v]]++; slot_of[v] = (int32_t)q; vtx[q] = HapVertex{0, 0, g->n_colours[v], v}; }
     }
-    // in-CSR of the renumbered vertices in scatter arrival order: (u asc, w desc, adjacency order asc)
-    std::vector<HapVertex> vtx(n);
-    for (int v = 0; v < n; ++v) vtx[new_of_old[v]] = HapVertex{0, 0, g->n_colours[v], v};
-    for (int64_t e = 0; e < E; ++e) vtx[new_of_old[g->out_dst[e]]].deg++;
+    for (int64_t e = 0; e < E; ++e) vtx[slot_of[g->out_dst[e]]].deg++;
     uint32_t run = 0;
     for (int q = 0; q < n; ++q) { vtx[q].e0 = run; run += vtx[q].deg; }
     std::vector<uint32_t> in_src((size_t)std::max<int64_t>(E, 1)), fill(n);
     for (int q = 0; q < n; ++q) fill[q] = vtx[q].e0;
     for (int u = 0; u < n; ++u)                                             // filled in (u asc, adjacency order asc)
-        for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) in_src[fill[new_of_old[g->out_dst[e]]]++] = (uint32_t)u | ((uint32_t)g->out_w[e] << 31);
-    // parallel edges of one source: the weight-1 ones arrive first (smaller source r), stably; then renumber the sources
-    for (int q = 0; q < n; ++q) {
+        for (int64_t e = g->out_off[u]; e < g->out_off[u + 1]; ++e) in_src[fill[slot_of[g->out_dst[e]]]++] = (uint32_t)u | ((uint32_t)g->out_w[e] << 31);
+    for (int q = 0; q < n; ++q) {       // parallel edges of one source: the weight-1 ones arrive first (smaller source r), stably
         uint32_t *a = in_src.data() + vtx[q].e0;
         for (uint32_t i = 0; i < vtx[q].deg;) {
             uint32_t j = i;
@@ -102,36 +99,25 @@ extern "C" int dg_dp_solve_haploid(dg_ctx *c, const dg_hap_graph *g, int32_t *dp
             if (j - i > 1) std::stable_partition(a + i, a + j, [](uint32_t x) { return (x >> 31) != 0; });
             i = j;
         }
-        for (uint32_t i = 0; i < vtx[q].deg; ++i) a[i] = (uint32_t)new_of_old[a[i] & 0x7FFFFFFFu] | (a[i] & 0x80000000u);
     }
     hipStream_t s = c->stream;
     const size_t N = (size_t)n * RP;
-    DevBuf d_lvl, d_vtx, d_in, d_old, d_dp, d_bv, d_br;
+    DevBuf d_lvl, d_vtx, d_in, d_dp, d_bv, d_br;
     if (int rc = d_lvl.ensure(4 * level_off.size())) return rc;
     if (int rc = d_vtx.ensure(sizeof(HapVertex) * (size_t)n)) return rc;
     if (int rc = d_in.ensure(4 * in_src.size())) return rc;
-    if (int rc = d_old.ensure(4 * (size_t)n)) return rc;
     if (int rc = d_dp.ensure(4 * N)) return rc;
     if (int rc = d_bv.ensure(4 * N)) return rc;
     if (int rc = d_br.ensure(4 * N)) return rc;
     DG_HIP(hipMemcpyAsync(d_lvl.p, level_off.data(), 4 * level_off.size(), hipMemcpyHostToDevice, s));
     DG_HIP(hipMemcpyAsync(d_vtx.p, vtx.data(), sizeof(HapVertex) * (size_t)n, hipMemcpyHostToDevice, s));
     DG_HIP(hipMemcpyAsync(d_in.p, in_src.data(), 4 * in_src.size(), hipMemcpyHostToDevice, s));
-    DG_HIP(hipMemcpyAsync(d_old.p, old_of_new.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(hap_dp_kernel, dim3(1), dim3(1024), 0, s, d_lvl.as<uint32_t>(), L, d_vtx.as<HapVertex>(), d_in.as<uint32_t>(), RP, d_dp.as<int32_t>(),
-                       d_bv.as<int32_t>(), d_br.as<int32_t>(), d_old.as<int32_t>());
+                       d_bv.as<int32_t>(), d_br.as<int32_t>());
     DG_HIP(hipGetLastError());
-    // download in renumbered order, hand back in the caller's vertex order
-    std::vector<int32_t> t_dp(N), t_bv(N), t_br(N);
-    DG_HIP(hipMemcpyAsync(t_dp.data(), d_dp.p, 4 * N, hipMemcpyDeviceToHost, s));
-    DG_HIP(hipMemcpyAsync(t_bv.data(), d_bv.p, 4 * N, hipMemcpyDeviceToHost, s));
-    DG_HIP(hipMemcpyAsync(t_br.data(), d_br.p, 4 * N, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(dp, d_dp.p, 4 * N, hipMemcpyDeviceToHost, s));          // tables are indexed by the caller's vertex ids
+    DG_HIP(hipMemcpyAsync(back_vtx, d_bv.p, 4 * N, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(back_r, d_br.p, 4 * N, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
-    for (int q = 0; q < n; ++q) {
-        const size_t o = (size_t)old_of_new[q] * RP, i = (size_t)q * RP;
-        memcpy(dp + o, t_dp.data() + i, 4 * (size_t)RP);
-        memcpy(back_vtx + o, t_bv.data() + i, 4 * (size_t)RP);
-        memcpy(back_r + o, t_br.data() + i, 4 * (size_t)RP);
-    }
     return DG_OK;
 }

@@ -137,7 +137,7 @@ int main(int argc, char **argv) {
     p.be.free_buf = dg_free;
     p.be.hint_dp_soon = b_hint;
     p.be.dp_solve_haploid = b_hap;
-    if (getenv("DG_HOST_HAPLOID")) p.opt.host_haploid = true;   // A/B and parity runs: the host gather loop
+    if (const char *hm = getenv("DG_HAPLOID")) p.opt.haploid_mode = !strcmp(hm, "host") ? 1 : (!strcmp(hm, "device") ? 2 : 0);   // default: by graph shape
     p.be.anchor_begin = b_anchor_begin;
     p.be.anchor_add_haplotype = b_anchor_add;
     p.be.anchor_finish = b_anchor_finish;

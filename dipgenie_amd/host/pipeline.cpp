@@ -869,7 +869,21 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R, std::string
     double th0 = now_s();
     const int n = g.n;
     HapTables T;
-    if (be.dp_solve_haploid && !opt.host_haploid) {                    // the device loop
+    // Device or host?  The tables are a chain of dependent levels (longest-path depth); on the device one workgroup walks
+    // it at ~0.7 us per level whatever its width, the host gather loop costs ~5 ns per (in-edge, r).  Graphs of this
+    // pipeline are a few vertices wide (MHC_4: 499 k vertices on 250 k levels: device 0.21 s, host 0.045 s), so `auto`
+    // goes to the device only when a level holds enough vertices to pay for its barrier.
+    bool on_device = be.dp_solve_haploid && opt.haploid_mode != 1;
+    if (on_device && opt.haploid_mode == 0) {
+        std::vector<int32_t> depth(n, 0);
+        int32_t deepest = 0;
+        for (int u = 0; u < n; ++u) {
+            for (int64_t e = g.adj_off[u]; e < g.adj_off[u + 1]; ++e) depth[g.adj_dst[e]] = std::max(depth[g.adj_dst[e]], depth[u] + 1);
+            deepest = std::max(deepest, depth[u]);
+        }
+        on_device = (double)g.adj_off[n] * (R + 1) / (double)(deepest + 1) >= 140.0 * 16;   // (in-edge, r) items per level vs 0.7 us of 16 host threads
+    }
+    if (on_device) {                                                   // the device loop
         std::vector<int32_t> ncol(n);
         for (int v = 0; v < n; ++v) ncol[v] = (int32_t)g.ncol(v);
         dg_hap_graph hg{n, R, g.adj_off.data(), g.adj_dst.data(), g.adj_w.data(), ncol.data()};

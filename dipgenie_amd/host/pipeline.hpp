@@ -53,7 +53,7 @@ struct Options {
     std::string dump_prefix;  // (ours) if set, dump the levelized DP graph to <prefix>.dpg
     bool dump_only = false;   // (ours, tests) stop after the dump
     std::string anchor_dump;  // (ours, tests) if set, write Anchor_hits + homo_bv as text (format of oracle/ref_harness.cpp `anchors`)
-    bool host_haploid = false;   // (ours, tests) keep the haploid (vertex, r) tables on the host even if the backend offers them
+    int haploid_mode = 0;        // (ours) haploid (vertex, r) tables: 0 = by graph shape, 1 = host gather loop, 2 = device (if the backend offers it)
     bool host_anchors = false;   // (ours, tests) keep the anchor join / filter / sort on the host even if the backend offers it
 };
 

@@ -414,6 +414,15 @@ def test_cli_e2e_mhc4_haploid(built_hip, gpu_ctx, tmp_path):
     assert hashlib.md5(fa).hexdigest() == c["fasta_md5"] == "0c4df87ded10634a36db0a2c90521ff0"
 
 
+def test_cli_e2e_mhc4_haploid_device_tables(built_hip, gpu_ctx, tmp_path):
+    """BASELINE configs[0] with the (vertex, r) tables forced onto the device (499 k vertices, 250 k dependent levels)"""
+    c = CASES["mhc4_p1"]
+    out = tmp_path / "o.fa"
+    subprocess.run([built_hip, "-t8"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, DG_HAPLOID="device"))
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == c["fasta_md5"] == "0c4df87ded10634a36db0a2c90521ff0"
+
+
 def test_dp_full_size_idempotent(gpu_ctx, built_hip, tmp_path):
     """size-independent properties at full size: re-running on the resident graph is bit-identical and
     a wider recombination budget never lowers the optimum."""
@@ -485,10 +494,10 @@ def test_haploid_rejects_unordered_graph(gpu_ctx):
 
 @pytest.mark.parametrize("name", ["toy2_p1", "toy1_p1", "bub_a_p1", "bub_c_p1"])
 def test_cli_haploid_device_equals_host_tables(built_hip, gpu_ctx, name, tmp_path):
-    """-p1 through the device (vertex, r) tables and through the host gather loop (DG_HOST_HAPLOID=1): same FASTA = the
-    reference's (tests/golden/e2e.json)"""
+    """-p1 through the device (vertex, r) tables (DG_HAPLOID=device; by default the CLI picks by graph shape, and these
+    narrow graphs go to the host gather loop) and through the host loop: same FASTA = the reference's (tests/golden/e2e.json)"""
     c = CASES[name]
-    for env_extra in ({}, {"DG_HOST_HAPLOID": "1"}):
+    for env_extra in ({"DG_HAPLOID": "device"}, {"DG_HAPLOID": "host"}, {}):
         out = tmp_path / "o.fa"
         subprocess.run([built_hip, "-t4"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, **env_extra))
