@@ -39,104 +39,80 @@ void Pipeline::stamp(const char *name, double t0) {
 // Solver::read_gfa  (solver.cpp:27-227)
 // ======================================================================================
 void Pipeline::read_gfa_from(const GfaGraph &g) {
+    // graph: one vertex per segment, forward-strand arcs only (:60-91); walks -> paths, named sample.hap (:108-125)
     n_vtx = g.n_seg();
-    node_seq.assign(g.seg_seq.begin(), g.seg_seq.end());               // :37-43
+    node_seq.assign(g.seg_seq.begin(), g.seg_seq.end());
     adj_list.assign(n_vtx, {});
-    for (uint32_t s = 0; s < n_vtx; ++s)                               // :60-91 forward strand only
-        for (uint32_t w : g.arcs[(size_t)2 * s]) adj_list[s].push_back(w >> 1);
-
-    num_walks = (uint32_t)g.walks.size();                              // :98
+    for (uint32_t seg = 0; seg < n_vtx; ++seg)
+        for (uint32_t arc : g.arcs[(size_t)2 * seg]) adj_list[seg].push_back(arc >> 1);
+    num_walks = (uint32_t)g.walks.size();
     paths.assign(num_walks, {});
-    hap_id2name.clear();
-    for (uint32_t w = 0; w < num_walks; ++w) {                         // :108-125
-        hap_id2name.push_back(g.walks[w].sample + "." + std::to_string(g.walks[w].hap));
-        for (uint32_t x : g.walks[w].v) {
-            if (x & 1) exit(1);                                        // :116-119 (silent, as the reference)
-            paths[w].push_back(x >> 1);
+    hap_id2name.assign(num_walks, std::string());
+    for (uint32_t w = 0; w < num_walks; ++w) {
+        hap_id2name[w] = g.walks[w].sample + "." + std::to_string(g.walks[w].hap);
+        paths[w].reserve(g.walks[w].v.size());
+        for (uint32_t oriented : g.walks[w].v) {
+            if (oriented & 1) exit(1);                                 // a reverse-strand step ends the run silently (:116-119)
+            paths[w].push_back(oriented >> 1);
         }
     }
-
-    const int32_t V = (int32_t)n_vtx;
-    const int64_t INF = std::numeric_limits<int64_t>::max() / 4;       // :131
-    std::vector<int64_t> pos(V, INF);
-    for (size_t w = 0; w < paths.size(); ++w) {
-        const auto &pw = paths[w];
-        for (int64_t t = 0; t < (int64_t)pw.size(); ++t) {
-            int32_t vtx = (int32_t)pw[t];
-            if (vtx < 0 || vtx >= V) continue;
-            if (t < pos[vtx]) pos[vtx] = t;
-        }
-    }
+    // MSA-like column of every vertex (:127-171): seeded with the earliest step index at which any walk visits it
+    // (vertices on no walk are parked one column past the largest seed), then raised until column[next] > column[prev]
+    // holds along every walk.  The least such assignment is a longest-path labelling of the walk-step graph: one pass
+    // in topological order when that graph is acyclic; otherwise the reference's sweep-until-stable loop, cap included.
+    const int32_t nv = (int32_t)n_vtx;
+    constexpr int64_t UNSEEN = std::numeric_limits<int64_t>::max() / 4;
+    std::vector<int64_t> column(nv, UNSEEN);
+    for (const auto &walk : paths)
+        for (size_t step = 0; step < walk.size(); ++step) column[walk[step]] = std::min(column[walk[step]], (int64_t)step);
     {
-        int64_t max_seed = -1;                                         // :146-153
-        for (int32_t v = 0; v < V; ++v) if (pos[v] != INF) max_seed = std::max(max_seed, pos[v]);
-        int64_t fallback_start = (max_seed >= 0 ? max_seed + 1 : 0);
-        for (int32_t v = 0; v < V; ++v) if (pos[v] == INF) pos[v] = fallback_start;
+        int64_t last_seed = -1;
+        for (int64_t c : column) if (c != UNSEEN) last_seed = std::max(last_seed, c);
+        for (int64_t &c : column) if (c == UNSEEN) c = last_seed + 1;
     }
-    // :158-171 relaxes pos[v] >= pos[u] + 1 over consecutive path steps until nothing changes.  That loop converges
-    // to the least fixed point above the seeds, which on an acyclic step graph is what one longest-path pass in
-    // topological order gives (dozens of whole-panel passes at 24 walks otherwise); a cyclic step graph keeps the
-    // literal loop, iteration cap included.
-    bool relaxed = false;
+    bool labelled = false;
     {
-        std::vector<int64_t> eoff((size_t)V + 1, 0);
-        for (const auto &pw : paths) for (size_t t = 1; t < pw.size(); ++t) eoff[pw[t - 1] + 1]++;
-        for (int32_t v = 0; v < V; ++v) eoff[v + 1] += eoff[v];
-        std::vector<int32_t> edst((size_t)eoff[V]), indeg(V, 0);
-        {
-            std::vector<int64_t> fill(eoff.begin(), eoff.end() - 1);
-            for (const auto &pw : paths) for (size_t t = 1; t < pw.size(); ++t) { edst[fill[pw[t - 1]]++] = (int32_t)pw[t]; indeg[pw[t]]++; }
-        }
-        std::vector<int32_t> queue;
-        queue.reserve(V);
-        for (int32_t v = 0; v < V; ++v) if (indeg[v] == 0) queue.push_back(v);
-        std::vector<int64_t> lp(pos);
-        for (size_t qi = 0; qi < queue.size(); ++qi) {
-            const int32_t u = queue[qi];
-            for (int64_t e = eoff[u]; e < eoff[u + 1]; ++e) {
-                const int32_t v = edst[e];
-                if (lp[v] < lp[u] + 1) lp[v] = lp[u] + 1;
-                if (--indeg[v] == 0) queue.push_back(v);
+        std::vector<int64_t> succ_off((size_t)nv + 1, 0);
+        for (const auto &walk : paths) for (size_t t = 1; t < walk.size(); ++t) succ_off[walk[t - 1] + 1]++;
+        for (int32_t v = 0; v < nv; ++v) succ_off[v + 1] += succ_off[v];
+        std::vector<int32_t> succ((size_t)succ_off[nv]), pending(nv, 0), order;
+        std::vector<int64_t> cursor(succ_off.begin(), succ_off.end() - 1);
+        for (const auto &walk : paths)
+            for (size_t t = 1; t < walk.size(); ++t) { succ[cursor[walk[t - 1]]++] = (int32_t)walk[t]; pending[walk[t]]++; }
+        order.reserve(nv);
+        for (int32_t v = 0; v < nv; ++v) if (!pending[v]) order.push_back(v);
+        std::vector<int64_t> raised(column);
+        for (size_t at = 0; at < order.size(); ++at) {
+            const int32_t u = order[at];
+            for (int64_t e = succ_off[u]; e < succ_off[u + 1]; ++e) {
+                raised[succ[e]] = std::max(raised[succ[e]], raised[u] + 1);
+                if (--pending[succ[e]] == 0) order.push_back(succ[e]);
             }
         }
-        if ((int32_t)queue.size() == V) { pos.swap(lp); relaxed = true; }
+        if ((int32_t)order.size() == nv) { column.swap(raised); labelled = true; }
     }
-    bool changed = !relaxed;
-    int iter = 0, iter_cap = std::max(10, V);
-    while (changed && iter++ < iter_cap) {
-        changed = false;
-        for (size_t w = 0; w < paths.size(); ++w) {
-            const auto &pw = paths[w];
-            for (size_t t = 1; t < pw.size(); ++t) {
-                int32_t u = (int32_t)pw[t - 1], v = (int32_t)pw[t];
-                if (u < 0 || u >= V || v < 0 || v >= V) continue;
-                int64_t need = pos[u] + 1;
-                if (pos[v] < need) { pos[v] = need; changed = true; }
-            }
-        }
+    for (int sweep = 0, cap = std::max(10, nv); !labelled && sweep < cap; ++sweep) {   // cyclic step graph (:158-171)
+        labelled = true;
+        for (const auto &walk : paths)
+            for (size_t t = 1; t < walk.size(); ++t)
+                if (column[walk[t]] <= column[walk[t - 1]]) { column[walk[t]] = column[walk[t - 1]] + 1; labelled = false; }
     }
-    std::vector<std::pair<int64_t, int32_t>> by_pos;                   // :174-199
-    by_pos.reserve(V);
-    for (int32_t v = 0; v < V; ++v) by_pos.emplace_back(pos[v], v);
-    std::sort(by_pos.begin(), by_pos.end());
-    std::vector<int32_t> dense_pos(V, -1);
-    int32_t cur_rank = -1;
-    int64_t prev_col = std::numeric_limits<int64_t>::min();
-    for (auto &p : by_pos) {
-        if (p.first != prev_col) { ++cur_rank; prev_col = p.first; }
-        dense_pos[p.second] = cur_rank;
+    // top_order_map (:174-199) = rank of the vertex in (column, id) order; adjacency lists (:216-223) sorted by (dense
+    // column rank, id).  Both are total orders, so one 64-bit key per vertex serves either sort.
+    std::vector<int32_t> by_column(nv);
+    std::iota(by_column.begin(), by_column.end(), 0);
+    std::stable_sort(by_column.begin(), by_column.end(), [&](int32_t x, int32_t y) { return column[x] < column[y]; });   // ids ascending inside a column
+    top_order_map.assign(nv, -1);
+    std::vector<uint64_t> sort_key(nv);
+    int64_t n_columns = -1, last_column = std::numeric_limits<int64_t>::min();
+    for (int32_t rank = 0; rank < nv; ++rank) {
+        const int32_t v = by_column[rank];
+        top_order_map[v] = rank;
+        if (column[v] != last_column) { ++n_columns; last_column = column[v]; }
+        sort_key[v] = ((uint64_t)n_columns << 32) | (uint32_t)v;
     }
-    top_order_map.assign(V, -1);
-    for (int32_t i = 0; i < (int32_t)by_pos.size(); ++i) top_order_map[by_pos[i].second] = i;
-
-    for (int32_t u = 0; u < V; ++u) {                                  // :216-223
-        auto &nei = adj_list[u];
-        std::sort(nei.begin(), nei.end(), [&](uint32_t a, uint32_t b) {
-            int32_t ca = dense_pos[a], cb = dense_pos[b];
-            if (ca != cb) return ca < cb;
-            return a < b;
-        });
-    }
+    for (auto &targets : adj_list)
+        std::sort(targets.begin(), targets.end(), [&](uint32_t x, uint32_t y) { return sort_key[x] < sort_key[y]; });
 }
 
 int Pipeline::load_graph(std::string &err) {
