@@ -176,7 +176,7 @@ def attach_profile(roof, launch_profile, workload):
     with open(path) as f:
         prof = json.load(f)
     if prof.get("launch_profile") != launch_profile:
-        roof["traffic_note"] = "profiles/r02_roofline.json was taken on a different set of sweep launches: stale, ignored (re-run tools/roofline_profile.sh)"
+        roof["traffic_note"] = "profiles/r02_roofline.json was taken on a different set of sweep launches: stale, ignored (re-run tools/roofline_profile.sh + tools/roofline_from_profiles.py)"
         return
     roof["traffic"] = prof["hbm_bytes_per_launch"]["high"]
     roof["traffic_unit"] = "bytes/launch"
