@@ -13,6 +13,14 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C dipgenie_amd/csrc` (or __graft_entry__.build()). "
         "dipgenie_amd has no CPU fallback."
     )
+# One HIP runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64 (ROCm 7.0) under the same sonames as
+# the system's (ROCm 7.2) that libdipgenie_hip.so is linked against, and the dynamic loader binds a soname to whichever
+# copy came first.  Loaded after this library, torch would get the system copy and then finds "No HIP GPUs"; loaded before
+# it, both share torch's copy (what bench.py, dist_sketch.py and the GPU tests need).  So where torch is installed it goes first.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
 lib = C.CDLL(LIB_PATH)
 
 

@@ -28,6 +28,10 @@ namespace dgi {
 constexpr int TW = 128;                 // windows per tile (2 per lane)
 constexpr int PLANE_WORDS = 12;         // 64-bit words per base bit plane: (TW + 255 + 255) / 64 + 2
 #define PLANE_OFF(k, w) ((8 * (TW + (w)) + 4 * (TW + 1) + (TW + (w)) + (TW + (w) + (k)) + 7) & ~7)
+// behind the planes: the window-minimum tables -- mc[TW + w] u64, ac[TW + 1] u64, mp[TW + w] u16, ap[TW + 1] u16
+#define TABLE_OFF(k, w) (PLANE_OFF(k, w) + 8 * 3 * PLANE_WORDS)
+// orders this wave's LDS traffic across lanes (LDS is in order per wave; this keeps the compiler from moving accesses)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 struct Tile {
     int64_t seq_start;                  // offset of the sequence in the bases buffer
@@ -164,8 +168,10 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         if (lane == 0) { plane[rd] = mlo; plane[PLANE_WORDS + rd] = mhi; plane[2 * PLANE_WORDS + rd] = minv; }
     }
     __syncthreads();
+    bool lane_inv = false;
     for (int q = lane; q < nkm; q += 64) {
         bool valid = (k <= 32) && bits_at(plane + 2 * PLANE_WORDS, q, k) == 0;
+        lane_inv |= !valid;
         int o;
         if (valid) {
             const uint32_t lo = bits_at(plane, q, k), hi = bits_at(plane + PLANE_WORDS, q, k);   // bit t = base q + t
@@ -186,51 +192,102 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
 
     // window minima (ties -> newest, solver.cpp:316)
     const int nw_all = active ? T.nwin + has_prev : 0;
-    for (int wi = lane; wi < nw_all; wi += 64) {
-        int best = wi;
-        bool allv = true;
-        for (int t = 0; t < w; ++t) allv = allv && (info[wi + t] & 1);
-        if (allv) {
-            uint64_t bc = code[wi];
-            for (int t = 1; t < w; ++t) { const uint64_t c = code[wi + t]; if (c <= bc) { bc = c; best = wi + t; } }
-        } else {
-            for (int t = 1; t < w; ++t)
-                if (cmp_canon(sq, k, wi + t, (info[wi + t] >> 1) & 1, best, (info[best] >> 1) & 1) <= 0) best = wi + t;
+    uint64_t *mc = (uint64_t *)(base + TABLE_OFF(k, w));               // [TW + w]
+    uint64_t *ac = mc + (TW + w);                                      // [TW + 1]
+    uint16_t *mp = (uint16_t *)(ac + (TW + 1));                        // [TW + w]
+    uint16_t *ap = mp + (TW + w);                                      // [TW + 1]
+    if (__ballot(lane_inv) == 0) {
+        // every k-mer of the tile is pure ACGT: minima by doubling.  m_L[q] = (smallest code, its newest position) over
+        // k-mers [q, q + L), built in place for L = 1, 2, 4, ... (m_2L[q] = m_L[q] (+) m_L[q + L], "later wins on <="); a
+        // window of w k-mers is the concatenation of one range per set bit of w, lowest bit first.  ~8 LDS round trips per
+        // k-mer instead of w of them.
+        for (int q = lane; q < nkm; q += 64) { mc[q] = code[q]; mp[q] = (uint16_t)q; }
+        WAVE_SYNC();
+        int off = 0;
+        bool first = true;
+        for (int L = 1; L <= w; L <<= 1) {
+            if (L > 1) {
+                const int h = L >> 1;
+                for (int q0 = 0; q0 < nkm; q0 += 64) {                 // ascending: a round only reads entries no round has rewritten yet
+                    const int q = q0 + lane;
+                    const bool ok = q + h < nkm;
+                    uint64_t c1 = 0, c2 = 0;
+                    uint16_t p2 = 0;
+                    if (ok) { c1 = mc[q]; c2 = mc[q + h]; p2 = mp[q + h]; }
+                    WAVE_SYNC();                                      // all loads of the round before its stores
+                    if (ok && c2 <= c1) { mc[q] = c2; mp[q] = p2; }
+                    WAVE_SYNC();
+                }
+            }
+            if (w & L) {
+                for (int wi = lane; wi < nw_all; wi += 64) {
+                    const uint64_t c2 = mc[wi + off];
+                    const uint16_t p2 = mp[wi + off];
+                    if (first || c2 <= ac[wi]) { ac[wi] = c2; ap[wi] = p2; }
+                }
+                off += L;
+                first = false;
+                WAVE_SYNC();
+            }
         }
-        wpos[wi] = best;
+        for (int wi = lane; wi < nw_all; wi += 64) wpos[wi] = (int32_t)ap[wi];
+    } else {
+        for (int wi = lane; wi < nw_all; wi += 64) {                   // tiles holding N / IUPAC bytes: plain scan, bytewise where needed
+            int best = wi;
+            bool allv = true;
+            for (int t = 0; t < w; ++t) allv = allv && (info[wi + t] & 1);
+            if (allv) {
+                uint64_t bc = code[wi];
+                for (int t = 1; t < w; ++t) { const uint64_t c = code[wi + t]; if (c <= bc) { bc = c; best = wi + t; } }
+            } else {
+                for (int t = 1; t < w; ++t)
+                    if (cmp_canon(sq, k, wi + t, (info[wi + t] >> 1) & 1, best, (info[best] >> 1) & 1) <= 0) best = wi + t;
+            }
+            wpos[wi] = best;
+        }
     }
     __syncthreads();
     if (!active) return;
 
-    // emission (solver.cpp:329-335 / 401-407)
-    int64_t wbase = MODE >= 1 ? tile_base[tile_id] : 0;
-    int64_t total = 0;
-    for (int round = 0; round * 64 < T.nwin; ++round) {
-        const int wi = round * 64 + lane;                // tile-local window (without the prev offset)
-        bool emit = false;
-        uint64_t H = 0;
-        int p = 0;
-        if (wi < T.nwin) {
-            p = wpos[wi + has_prev];
+    // emission (solver.cpp:329-335 / 401-407): a minimizer is emitted where its hash differs from the previous window's.
+    // Windows sharing their argmin form runs; every run's k-mer is hashed ONCE (one lane per run), then run j is emitted iff
+    // its hash differs from run j - 1's (run 0 of a tile that continues a sequence is the previous tile's last window: context
+    // only; run 0 of a sequence's first tile compares with prev_hash = UINT64_MAX).
+    uint16_t *run_w = mp;                                              // first window of every run
+    uint64_t *run_h = mc;                                              // its hash
+    int n_runs = 0;
+    for (int q0 = 0; q0 < nw_all; q0 += 64) {
+        const int wi = q0 + lane;
+        const bool head = wi < nw_all && (wi == 0 || wpos[wi] != wpos[wi - 1]);
+        const unsigned long long m = __ballot(head);
+        if (head) run_w[n_runs + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint16_t)wi;
+        n_runs += __popcll(m);
+    }
+    WAVE_SYNC();
+    for (int j0 = 0; j0 < n_runs; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < n_runs) {
+            const int p = wpos[run_w[j]];
             const int op = (info[p] >> 1) & 1;
             const bool vp = info[p] & 1;
             const uint64_t cp = code[p];
             // (ACGT-only k-mers are hashed from their code: no LDS byte gathers)
             auto bp = [&](int t) -> uint8_t { return vp ? code_byte(cp, k, t) : canon_byte(sq, p, k, op, t); };
-            if (T.win0 + wi == 0) {                      // first window of the sequence: prev_hash = UINT64_MAX
-                H = murmur3_fold(bp, k);
-                emit = H != UINT64_MAX;
-            } else {
-                const int q = wpos[wi + has_prev - 1];
-                if (q != p) {
-                    const int oq = (info[q] >> 1) & 1;
-                    const bool vq = info[q] & 1;
-                    const uint64_t cq = code[q];
-                    auto bq = [&](int t) -> uint8_t { return vq ? code_byte(cq, k, t) : canon_byte(sq, q, k, oq, t); };
-                    H = murmur3_fold(bp, k);
-                    emit = H != murmur3_fold(bq, k);
-                }
-            }
+            run_h[j] = murmur3_fold(bp, k);
+        }
+    }
+    WAVE_SYNC();
+    int64_t wbase = MODE >= 1 ? tile_base[tile_id] : 0;
+    int64_t total = 0;
+    for (int j0 = has_prev; j0 < n_runs; j0 += 64) {
+        const int j = j0 + lane;
+        bool emit = false;
+        uint64_t H = 0;
+        int p = 0;
+        if (j < n_runs) {
+            H = run_h[j];
+            p = wpos[run_w[j]];
+            emit = H != (j == 0 ? UINT64_MAX : run_h[j - 1]);
         }
         const unsigned long long m = __ballot(emit);
         if (MODE >= 1 && emit) {
@@ -372,7 +429,7 @@ static SketchState &state(dg_ctx *c) {
 }
 
 static size_t lds_per_wave(int k, int w) {
-    size_t b = (size_t)PLANE_OFF(k, w) + 8 * 3 * (size_t)PLANE_WORDS;
+    size_t b = (size_t)TABLE_OFF(k, w) + 8 * (size_t)(TW + w) + 8 * (size_t)(TW + 1) + 2 * (size_t)(TW + w) + 2 * (size_t)(TW + 1) + 8;
     return (b + 15) & ~(size_t)15;
 }
 
