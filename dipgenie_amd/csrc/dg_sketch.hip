@@ -29,7 +29,9 @@ constexpr int TW = 128;                 // windows per tile (2 per lane)
 constexpr int PLANE_WORDS = 12;         // 64-bit words per base bit plane: (TW + 255 + 255) / 64 + 2
 #define PLANE_OFF(k, w) ((8 * (TW + (w)) + 4 * (TW + 1) + (TW + (w)) + (TW + (w) + (k)) + 7) & ~7)
 // behind the planes: the window-minimum tables -- mc[TW + w] u64, ac[TW + 1] u64, mp[TW + w] u16, ap[TW + 1] u16
-#define TABLE_OFF(k, w) (PLANE_OFF(k, w) + 8 * 3 * PLANE_WORDS)
+// behind the planes: the 2-bit base stream (base t at bits [2t, 2t + 1]), 2 words per 64 bases
+#define STREAM_OFF(k, w) (PLANE_OFF(k, w) + 8 * 3 * PLANE_WORDS)
+#define TABLE_OFF(k, w) (STREAM_OFF(k, w) + 8 * (2 * PLANE_WORDS + 1))
 // orders this wave's LDS traffic across lanes (LDS is in order per wave; this keeps the compiler from moving accesses)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -120,6 +122,56 @@ __device__ __forceinline__ uint32_t bits_at(const uint64_t *m, int q, int n) {
     if (sh) v |= m[wd + 1] << (64 - sh);
     return (uint32_t)(v & ((n >= 32) ? 0xFFFFFFFFULL : ((1ULL << n) - 1ULL)));
 }
+// 2k bits starting at bit 2q of the base stream: base q + t of the sequence at bits [2t, 2t + 1]
+__device__ __forceinline__ uint64_t stream_at(const uint64_t *st, int q, int k) {
+    const int wd = q >> 5, sh = (q & 31) << 1;
+    uint64_t v = st[wd] >> sh;
+    if (sh) v |= st[wd + 1] << (64 - sh);
+    return k >= 32 ? v : (v & ((1ULL << (2 * k)) - 1ULL));
+}
+// reverses the order of the k 2-bit digits of x
+__device__ __forceinline__ uint64_t reverse_digits(uint64_t x, int k) {
+    uint64_t b = __brevll(x) >> (64 - 2 * k);                         // bits reversed: digits reversed, each digit's two bits swapped
+    return ((b & 0xAAAAAAAAAAAAAAAAULL) >> 1) | ((b & 0x5555555555555555ULL) << 1);
+}
+// eight 2-bit codes (digit j of d = byte j of the result) -> eight ASCII bytes "ACGT"[code]
+__device__ __forceinline__ uint64_t ascii8(uint32_t d) {
+    uint64_t y = d & 0xFFFFu;
+    y = (y | (y << 24)) & 0x000000FF000000FFULL;
+    y = (y | (y << 12)) & 0x000F000F000F000FULL;
+    y = (y | (y << 6)) & 0x0303030303030303ULL;
+    const uint64_t h = (y >> 1) & 0x0101010101010101ULL;               // code >= 2
+    return 0x4141414141414141ULL + 2 * y + 2 * h + 0x0B * (h & y);     // A 41, C 43, G 47 (41+4+2), T 54 (41+6+2+0B)
+}
+// MurmurHash3_x64_128 (h1^h2, seed 0) of the k ASCII bytes of a pure-ACGT k-mer given as its 2-bit code (first base most
+// significant), k <= 32: the 8-byte words are generated from the code, no per-byte loop
+__device__ __forceinline__ uint64_t murmur3_code(uint64_t code, int k) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    const uint64_t rd = reverse_digits(code, k);                       // base t at digit t
+    auto word = [&](int first) -> uint64_t {                           // bytes first .. first+7 of the key (bytes past k are 0)
+        const int left = k - first;
+        if (left <= 0) return 0ULL;
+        uint64_t a = ascii8((uint32_t)(rd >> (2 * first)));
+        return left >= 8 ? a : (a & ((1ULL << (8 * left)) - 1ULL));
+    };
+    uint64_t h1 = 0, h2 = 0;
+    const int nblocks = k >> 4;
+    for (int b = 0; b < nblocks; ++b) {
+        uint64_t k1 = word(16 * b), k2 = word(16 * b + 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const int tail = nblocks << 4, rem = k & 15;
+    if (rem > 8) { uint64_t k2 = word(tail + 8); k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    if (rem > 0) { uint64_t k1 = word(tail); k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    return h1 ^ h2;
+}
 // byte t of a k-mer given as 2-bit code (first base most significant)
 __device__ __forceinline__ uint8_t code_byte(uint64_t code, int k, int t) {
     return (uint8_t)(0x54474341u >> (8 * (int)((code >> (2 * (k - 1 - t))) & 3ULL)));   // "ACGT"
@@ -158,14 +210,17 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     // lexicographic order; A<C<G<T matches ASCII).  The bases are turned into three bit planes with wave ballots (low
     // code bit, high code bit, "not ACGT"), so a k-mer's forward and reverse-complement codes are two bit-field
     // extractions + an interleave instead of a k-step loop over LDS bytes.
-    uint64_t *plane = (uint64_t *)(base + PLANE_OFF(k, w));           // [3][PLANE_WORDS]: low code bit, high code bit, not-ACGT
+    uint64_t *plane = (uint64_t *)(base + PLANE_OFF(k, w));           // [3][PLANE_WORDS]: (unused), (unused), not-ACGT
+    uint64_t *stream = (uint64_t *)(base + STREAM_OFF(k, w));         // [2 * PLANE_WORDS + 1]: 2-bit codes, base t at bits [2t, 2t + 1]
     if (lane < 3 * PLANE_WORDS) plane[lane] = 0;
+    if (lane < 2 * PLANE_WORDS + 1) stream[lane] = 0;
     __syncthreads();
     for (int rd = 0; rd * 64 < nb; ++rd) {
         const int t = rd * 64 + lane;
         const int cf = t < nb ? code2(sq[t]) : -1;
         const unsigned long long mlo = __ballot(cf >= 0 && (cf & 1)), mhi = __ballot(cf >= 0 && (cf & 2)), minv = __ballot(t < nb && cf < 0);
-        if (lane == 0) { plane[rd] = mlo; plane[PLANE_WORDS + rd] = mhi; plane[2 * PLANE_WORDS + rd] = minv; }
+        if (lane == 0) { plane[2 * PLANE_WORDS + rd] = minv; stream[2 * rd] = spread32(mlo) | (spread32(mhi) << 1); }
+        if (lane == 1) stream[2 * rd + 1] = spread32(mlo >> 32) | (spread32(mhi >> 32) << 1);
     }
     __syncthreads();
     bool lane_inv = false;
@@ -174,12 +229,12 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         lane_inv |= !valid;
         int o;
         if (valid) {
-            const uint32_t lo = bits_at(plane, q, k), hi = bits_at(plane + PLANE_WORDS, q, k);   // bit t = base q + t
-            const uint32_t msk = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
-            // forward: base 0 most significant -> reverse the k-bit fields; reverse complement: base t at digit t, complemented
-            const uint32_t rlo = __brev(lo) >> (32 - k), rhi = __brev(hi) >> (32 - k);
-            const uint64_t f = spread32(rlo) | (spread32(rhi) << 1);
-            const uint64_t r = spread32(~lo & msk) | (spread32(~hi & msk) << 1);
+            // base t of the k-mer at digit t = the reverse complement's digits once complemented (base k-1-t' complemented
+            // is its digit t'... read from the top); the forward code wants base 0 most significant: digits reversed
+            const uint64_t x = stream_at(stream, q, k);
+            const uint64_t msk = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+            const uint64_t r = ~x & msk;
+            const uint64_t f = reverse_digits(x, k);
             o = r < f ? 1 : 0;
             code[q] = o ? r : f;
         } else {
@@ -271,9 +326,12 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             const int op = (info[p] >> 1) & 1;
             const bool vp = info[p] & 1;
             const uint64_t cp = code[p];
-            // (ACGT-only k-mers are hashed from their code: no LDS byte gathers)
-            auto bp = [&](int t) -> uint8_t { return vp ? code_byte(cp, k, t) : canon_byte(sq, p, k, op, t); };
-            run_h[j] = murmur3_fold(bp, k);
+            if (vp) {
+                run_h[j] = murmur3_code(cp, k);                        // pure ACGT: the key's words come straight from the code
+            } else {
+                auto bp = [&](int t) -> uint8_t { return canon_byte(sq, p, k, op, t); };
+                run_h[j] = murmur3_fold(bp, k);
+            }
         }
     }
     WAVE_SYNC();
