@@ -233,19 +233,29 @@ __device__ __forceinline__ void merge_best(int ov, uint32_t oo, bool same, int &
 #define DG_PROBE_END do { } while (0)
 #endif
 
+// What a task's FIRST load round needs, as leading scalar kernel arguments: the command processor preloads the first 16
+// dwords of scalar arguments into SGPRs (-mllvm -amdgpu-kernarg-preload-count, by-value structs stop the preload), so the
+// row / slot / in-edge-matrix loads issue without waiting for a load of the kernel-argument segment.
+struct LevelHead {
+    const uint4 *rowrec_l;              // rowrec + b0
+    const uint2 *slots_l;               // slots + slot_first
+    const uint32_t *rowx_l;             // rowx + rowx_off
+    int rowx_stride;
+};
+
 template <int RC, bool DIGEST, bool GENERAL, int COOP>
-__device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
+__device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
                                            int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr) {
     const int lane = threadIdx.x & 63;
     const int RP = A.RP;
     DG_PROBE_BEGIN
     DG_PROBE(0);
     // first load round: every address below comes from kernel arguments and the block index alone
-    const uint4 rr = A.rowrec[d.b0 + i2];                               // {eu0, du, pu0, pu1}
-    uint2 sl = A.slots[d.slot_first + (int64_t)g * 64 + lane];
-    const bool rowx = !GENERAL && d.rowx_stride > 0;
+    const uint4 rr = H.rowrec_l[i2];                                    // {eu0, du, pu0, pu1}
+    uint2 sl = H.slots_l[g * 64 + lane];
+    const bool rowx = !GENERAL && H.rowx_stride > 0;
     uint32_t mypu = 0;                                                  // in-edge words of the row, one per lane
-    if (rowx && lane < d.rowx_stride) mypu = A.rowx[d.rowx_off + (int64_t)i2 * d.rowx_stride + lane];
+    if (rowx && lane < H.rowx_stride) mypu = H.rowx_l[i2 * H.rowx_stride + lane];
     // steps field: 0..6 = log2 steps of the segmented max; 15 = first block of a giant column (in-degree > 64: its
     // in-edges fill several consecutive blocks, all walked by THIS wave); 14 = continuation block (nothing to do)
     int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
@@ -255,7 +265,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
         if (steps == 14) return;                                        // (workgroup-uniform in the cooperative region: same g)
         if (steps == 15) {
             const int col = __builtin_amdgcn_readfirstlane(j2);
-            nblk = ((int)A.rowrec[d.b0 + col].y + 63) >> 6;
+            nblk = ((int)H.rowrec_l[col].y + 63) >> 6;
             steps = 6;
         }
     }
@@ -277,7 +287,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
     // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding; the select
     // discards what is out of range, which lets every load be issued unconditionally, back to back.
     for (int blk = 0; blk < (GENERAL ? nblk : 1); ++blk) {
-        if (GENERAL && blk > 0) sl = A.slots[d.slot_first + (int64_t)(g + blk) * 64 + lane];
+        if (GENERAL && blk > 0) sl = H.slots_l[(g + blk) * 64 + lane];
         const bool actb = sl.x != 0xFFFFFFFFu;
         act |= actb;
         const int j = (int)(sl.x & 0x7FFFu), wv = (int)((sl.x >> 15) & 1u);
@@ -388,7 +398,7 @@ __device__ __forceinline__ void sweep_task(const FastArgs &A, const LevelDesc &d
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
                     const uint32_t ru = BP_MAX_RANK - (bord[q] >> 8), rv = BP_MAX_RANK - (bord[q] & 0xFFu);
                     const uint32_t pi = A.in_edge[rr.x + ru] & 0x7FFFFFFFu;
-                    const uint32_t pj = A.in_edge[A.rowrec[d.b0 + j2].x + rv] & 0x7FFFFFFFu;
+                    const uint32_t pj = A.in_edge[H.rowrec_l[j2].x + rv] & 0x7FFFFFFFu;
                     dsum += digest_term(bval[q], o, pi, pj);
                 }
             }
@@ -419,11 +429,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 // per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2 [+ 4 per heavy row]), one task per wave (a 3-D
 // grid: splitting a combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
 template <int RC, bool DIGEST, bool GENERAL, bool COOP = false>
-__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDesc d, int lvl, const int32_t *__restrict__ heavy_rows = nullptr) {
+__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, int rowx_stride, int nblocks, int k2,
+                                                            int n_heavy, unsigned long long heavy_lo, unsigned long long heavy_hi,   // 14 dwords: preloaded
+                                                            FastArgs A, LevelDesc d, int lvl, const int32_t *__restrict__ heavy_rows) {
+    const LevelHead H{rowrec_l, slots_l, rowx_l, rowx_stride};
     const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
-    const int zc = COOP ? 4 * d.n_heavy : 0;                            // cooperative region: z < 4 n_heavy
+    const int zc = COOP ? 4 * n_heavy : 0;                              // cooperative region: z < 4 n_heavy
     if (COOP && (int)blockIdx.z < zc) {
         // cooperative region (blockDim = 4 waves): workgroup z = 4 h + b = slot block 4 x + b of the h-th heavy row.  It is
         // dispatched FIRST: its tasks (load round + LDS merge) are the longest of the launch, and started last they were
@@ -431,21 +444,20 @@ __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(FastArgs A, LevelDes
         __shared__ uint2 ex[3 * RC * 64];
         const int hz = (int)blockIdx.z;
         const int g = (int)blockIdx.x * 4 + (hz & 3);
-        if (g >= d.nblocks) return;                                     // workgroup-uniform: nobody is left at the barrier
+        if (g >= nblocks) return;                                       // workgroup-uniform: nobody is left at the barrier
         const int h = hz >> 2;
-        int i2;                                                         // the first heavy rows ride in the kernel arguments: no dependent load
-        switch (h) {
-            case 0: i2 = d.heavy_in[0]; break; case 1: i2 = d.heavy_in[1]; break; case 2: i2 = d.heavy_in[2]; break; case 3: i2 = d.heavy_in[3]; break;
-            case 4: i2 = d.heavy_in[4]; break; case 5: i2 = d.heavy_in[5]; break; case 6: i2 = d.heavy_in[6]; break; case 7: i2 = d.heavy_in[7]; break;
-            default: i2 = heavy_rows[d.heavy_first + h]; break;
-        }
-        sweep_task<RC, DIGEST, GENERAL, 2>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, (int)(threadIdx.x >> 6), ex);
+        int i2;                                                         // the first heavy rows ride in the kernel arguments (16 bits each): no dependent load
+        if (h < 4) i2 = (int)((heavy_lo >> (16 * h)) & 0xFFFFu);
+        else if (h < HEAVY_INLINE) i2 = (int)((heavy_hi >> (16 * (h - 4))) & 0xFFFFu);
+        else i2 = heavy_rows[d.heavy_first + h];
+        sweep_task<RC, DIGEST, GENERAL, 2>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, (int)(threadIdx.x >> 6), ex);
         return;
     }
-    const int g = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
-    if (g >= d.nblocks) return;                                         // wave-uniform; no block barrier below
+    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);         // always launched with 4 waves (reading blockDim would be a kernel-argument load)
+    if (g >= nblocks) return;                                           // wave-uniform; no block barrier below
     const int i2 = (int)blockIdx.z - zc;
-    sweep_task<RC, DIGEST, GENERAL, COOP ? 1 : 0>(A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    (void)k2;
+    sweep_task<RC, DIGEST, GENERAL, COOP ? 1 : 0>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
 }
 
 // Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
@@ -531,11 +543,16 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
         const int32_t *hv = S.d_heavy.as<int32_t>();
         const FastArgs &F = X.F;
+        const uint4 *rowrec_l = F.rowrec + d.b0;
+        const uint2 *slots_l = F.slots + d.slot_first;
+        const uint32_t *rowx_l = F.rowx + d.rowx_off;
+        unsigned long long hlo = 0, hhi = 0;
+        for (int q = 0; q < 4; ++q) { hlo |= (unsigned long long)(uint16_t)d.heavy_in[q] << (16 * q); hhi |= (unsigned long long)(uint16_t)d.heavy_in[4 + q] << (16 * q); }
         S.launch_hist[(rc & 63) * 4 + (d.fast_ok == 2 ? 2 : 0) + (coop ? 1 : 0)]++;
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
-#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, F, d, l, hv); } while (0)
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); } while (0)
+#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); } while (0)
 #define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
                                                     default: DG_COOP(4, DG); break; } break; } \
                             switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \
