@@ -343,7 +343,7 @@ extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
         if (!n) continue;
         char item[96];
         if (q == 0) snprintf(item, sizeof item, "dp_sweep_kernel:%lld", (long long)n);
-        else snprintf(item, sizeof item, "dp_sweep_fast_kernel<%d,%s,%s>:%lld", q / 4, (q & 2) ? "general" : "lean", (q & 1) ? "coop" : "plain", (long long)n);
+        else snprintf(item, sizeof item, "dp_sweep_%s_kernel<%d,%s>:%lld", (q & 1) ? "coop" : "fast", q / 4, (q & 2) ? "general" : "lean", (long long)n);
         if (!out.empty()) out += ' ';
         out += item;
     }

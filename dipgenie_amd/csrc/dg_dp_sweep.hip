@@ -233,21 +233,26 @@ __device__ __forceinline__ void merge_best(int ov, uint32_t oo, bool same, int &
 #define DG_PROBE_END do { } while (0)
 #endif
 
-// What a task's FIRST load round needs, as leading scalar kernel arguments: the command processor preloads the first 16
-// dwords of scalar arguments into SGPRs (-mllvm -amdgpu-kernarg-preload-count, by-value structs stop the preload), so the
-// row / slot / in-edge-matrix loads issue without waiting for a load of the kernel-argument segment.
+// What a task needs before its stores, as leading scalar kernel arguments: the command processor preloads the first 16
+// dwords of scalar arguments into SGPRs (-mllvm -amdgpu-kernarg-preload-count; by-value structs stop the preload), so
+// neither load round waits for a load of the kernel-argument segment (a cold miss on every CU at every launch: 0.3-0.4 us
+// per level when the first round had to wait for it).  Plain launches preload everything below; cooperative launches
+// spend five of the sixteen dwords on the heavy-row list and read {dm, pad_bytes, dT, buf_bytes} the ordinary way.
 struct LevelHead {
     const uint4 *rowrec_l;              // rowrec + b0
     const uint2 *slots_l;               // slots + slot_first
     const uint32_t *rowx_l;             // rowx + rowx_off
-    int rowx_stride;
+    const int32_t *cur;                 // padded start of the source level's state buffer
+    const uint16_t *dm;                 // delta matrix biased by -in_base * dT (entry of in-edge pair (e_u, e_v): dm[e_u * dT + dcol]); the zero slot if dT = 0
+    int rowx_stride, RP, k, pad_bytes, dT;
+    uint32_t buf_bytes;
 };
 
 template <int RC, bool DIGEST, bool GENERAL, int COOP>
 __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
                                            int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int RP = A.RP;
+    const int RP = H.RP;
     DG_PROBE_BEGIN
     DG_PROBE(0);
     // first load round: every address below comes from kernel arguments and the block index alone
@@ -269,9 +274,9 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
             steps = 6;
         }
     }
-    const bool has_delta = d.delta_off >= 0;
-    const uint16_t *dm = has_delta ? A.delta + d.delta_off : A.delta_zero;   // (A.delta is biased by the resident delta window)
-    const int dT = has_delta ? d.T : 0;
+    const uint16_t *dm = H.dm;
+    const int dT = H.dT;
+    const bool has_delta = dT != 0;
     const int du = (int)rr.y;
     if (COOP == 1 && du > COOP_MIN) return;
     DG_PROBE(1);
@@ -280,8 +285,8 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
     uint32_t bord[RC];
 #pragma unroll
     for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
-    const int64_t erow0 = (int64_t)(rr.x - d.in_base) * dT;
-    const int rowbytes = d.k * 4;
+    const int64_t erow0 = (int64_t)rr.x * dT;                           // (dm is biased by the level's first in-edge)
+    const int rowbytes = H.k * 4;
     bool act = false;
     // Source rows are r = r2 - w.  Byte offsets are relative to the padded buffer start (the resource), so rows
     // r = -1, -2 land in the front padding and r2 >= RP (ragged last chunk) in the tail padding; the select
@@ -298,8 +303,8 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
             if (actb && du > 0) {
                 const int ia = (int)(rr.z & 0x7FFFu), wa = (int)(rr.z >> 31) + wv;    // (bit 16: flag for the chain walk)
                 const int ib = (int)(rr.w & 0x7FFFu), wb = (int)(rr.w >> 31) + wv;
-                const int offa = ((ia * RP + (r0 - wa)) * d.k + j) * 4 + A.pad_bytes;
-                const int offb = ((ib * RP + (r0 - wb)) * d.k + j) * 4 + A.pad_bytes;
+                const int offa = ((ia * RP + (r0 - wa)) * H.k + j) * 4 + H.pad_bytes;
+                const int offb = ((ib * RP + (r0 - wb)) * H.k + j) * 4 + H.pad_bytes;
                 int va[RC], vb[RC];
                 const int dla = (int)dm[erow0 + dcol];
                 int dlb = 0;
@@ -334,7 +339,7 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
                                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mypu, t + u - c0);
                                 wmask |= (p >> 31) << u;
                                 const int iu = (int)(p & 0x7FFFFFFFu), w = (int)(p >> 31) + wv;
-                                const int off = ((iu * RP + (r0 - w)) * d.k + j) * 4 + A.pad_bytes;
+                                const int off = ((iu * RP + (r0 - w)) * H.k + j) * 4 + H.pad_bytes;
                                 dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
 #pragma unroll
                                 for (int q = 0; q < RC; ++q) vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, off + q * rowbytes, 0, 0);
@@ -428,19 +433,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 
 // per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2 [+ 4 per heavy row]), one task per wave (a 3-D
 // grid: splitting a combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
-template <int RC, bool DIGEST, bool GENERAL, bool COOP = false>
-__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, int rowx_stride, int nblocks, int k2,
-                                                            int n_heavy, unsigned long long heavy_lo, unsigned long long heavy_hi,   // 14 dwords: preloaded
-                                                            FastArgs A, LevelDesc d, int lvl, const int32_t *__restrict__ heavy_rows) {
-    const LevelHead H{rowrec_l, slots_l, rowx_l, rowx_stride};
-    const int32_t *cur = ((lvl - 1) & 1) ? A.base1 : A.base0;           // padded allocation starts
+template <int RC, bool DIGEST, bool GENERAL>
+__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
+                                                            int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
+                                                            FastArgs A, LevelDesc d, int lvl) {
+    const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
+    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);         // always launched with 4 waves (reading blockDim would be a kernel-argument load)
+    if (g >= nblocks) return;                                           // wave-uniform; no block barrier below
+    int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    sweep_task<RC, DIGEST, GENERAL, 0>(H, A, d, state_rsrc(cur, buf_bytes), nxt, (int)blockIdx.z, g, (int)blockIdx.y * RC, lvl);
+}
+
+// the same with a cooperative region: workgroup z < 4 n_heavy = slot block 4 x + (z & 3) of heavy row z >> 2, its four waves
+// walk a quarter of the row's in-edges each.  The region is dispatched FIRST: its tasks (load round + LDS merge) are the
+// longest of the launch, and started last they were the launch's tail (-3.6 % on the MHC-24 sweep against z >= k2).
+template <int RC, bool DIGEST, bool GENERAL>
+__global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur,
+                                                            int rowx_stride, int nblocks, int n_heavy, int rp_k, unsigned long long heavy_lo,
+                                                            unsigned long long heavy_hi,                                                  // 16 dwords: preloaded
+                                                            FastArgs A, LevelDesc d, int lvl, const uint16_t *dm, int dT, const int32_t *__restrict__ heavy_rows) {
+    const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, A.pad_bytes, dT, A.buf_bytes};
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
-    const int zc = COOP ? 4 * n_heavy : 0;                              // cooperative region: z < 4 n_heavy
-    if (COOP && (int)blockIdx.z < zc) {
-        // cooperative region (blockDim = 4 waves): workgroup z = 4 h + b = slot block 4 x + b of the h-th heavy row.  It is
-        // dispatched FIRST: its tasks (load round + LDS merge) are the longest of the launch, and started last they were
-        // the launch's tail (-3.6 % on the MHC-24 sweep against the region at z >= k2)
+    const int zc = 4 * n_heavy;
+    if ((int)blockIdx.z < zc) {
         __shared__ uint2 ex[3 * RC * 64];
         const int hz = (int)blockIdx.z;
         const int g = (int)blockIdx.x * 4 + (hz & 3);
@@ -453,11 +469,9 @@ __global__ __launch_bounds__(256) void dp_sweep_fast_kernel(const uint4 *rowrec_
         sweep_task<RC, DIGEST, GENERAL, 2>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl, (int)(threadIdx.x >> 6), ex);
         return;
     }
-    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);         // always launched with 4 waves (reading blockDim would be a kernel-argument load)
+    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (g >= nblocks) return;                                           // wave-uniform; no block barrier below
-    const int i2 = (int)blockIdx.z - zc;
-    (void)k2;
-    sweep_task<RC, DIGEST, GENERAL, COOP ? 1 : 0>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, i2, g, r0, lvl);
+    sweep_task<RC, DIGEST, GENERAL, 1>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, (int)blockIdx.z - zc, g, r0, lvl);
 }
 
 // Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
@@ -546,13 +560,16 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const uint4 *rowrec_l = F.rowrec + d.b0;
         const uint2 *slots_l = F.slots + d.slot_first;
         const uint32_t *rowx_l = F.rowx + d.rowx_off;
+        const int32_t *cur = ((l - 1) & 1) ? F.base1 : F.base0;
+        const int dT = d.delta_off >= 0 ? d.T : 0;
+        const uint16_t *dm = dT ? F.delta + d.delta_off - (int64_t)d.in_base * dT : F.delta_zero;   // (F.delta is biased by the resident delta window)
+        const int rp_k = S.RP | (d.k << 13);
         unsigned long long hlo = 0, hhi = 0;
         for (int q = 0; q < 4; ++q) { hlo |= (unsigned long long)(uint16_t)d.heavy_in[q] << (16 * q); hhi |= (unsigned long long)(uint16_t)d.heavy_in[4 + q] << (16 * q); }
-        S.launch_hist[(rc & 63) * 4 + (d.fast_ok == 2 ? 2 : 0) + (coop ? 1 : 0)]++;
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); } while (0)
-#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, d.rowx_stride, d.nblocks, d.k2, d.n_heavy, hlo, hhi, F, d, l, hv); } while (0)
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); } while (0)
+#define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_coop_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, d.rowx_stride, d.nblocks, d.n_heavy, rp_k, hlo, hhi, F, d, l, dm, dT, hv); \
+                              else hipLaunchKernelGGL((dp_sweep_coop_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, d.rowx_stride, d.nblocks, d.n_heavy, rp_k, hlo, hhi, F, d, l, dm, dT, hv); } while (0)
 #define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \
                                                     default: DG_COOP(4, DG); break; } break; } \
                             switch (rc) { case 1: DG_FAST(1, DG); break; case 2: DG_FAST(2, DG); break; case 3: DG_FAST(3, DG); break; \

@@ -19,9 +19,9 @@ PEAK = 8000.0
 
 
 def variant(name):
-    m = re.search(r"dp_sweep_fast_kernel<(\d+), (false|true), (false|true), (false|true)>", name)
+    m = re.search(r"dp_sweep_(fast|coop)_kernel<(\d+), (false|true), (false|true)>", name)
     if m:
-        return f"dp_sweep_fast_kernel<{m.group(1)},{'general' if m.group(3) == 'true' else 'lean'},{'coop' if m.group(4) == 'true' else 'plain'}>"
+        return f"dp_sweep_{m.group(1)}_kernel<{m.group(2)},{'general' if m.group(4) == 'true' else 'lean'}>"
     return "dp_sweep_kernel" if "dp_sweep_kernel<" in name else None
 
 
