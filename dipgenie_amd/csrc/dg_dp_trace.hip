@@ -3,7 +3,7 @@
 // load per level, so everything else is kept off it: the level descriptors of the next 64 levels are fetched one per
 // lane and broadcast with readlane, and the hop words are parked in path[].  In segmented mode it is called once per
 // chunk, last chunk first, carrying the cell in ChainState.
-// Finish kernel (1024 threads, levels in parallel): re-derive s_het from the colour lists of the winning edge pairs
+// Finish kernel (whole grid, levels in parallel): re-derive s_het from the colour lists of the winning edge pairs
 // (:662) and emit the weighted edges (:673-692; both final edges unconditionally) as (level, from, to, which) records;
 // the host orders them by level.
 #include <algorithm>
@@ -144,42 +144,35 @@ __global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc
     if (lane == 0) { st->i = W.i; st->j = W.j; st->r = W.r; st->value = W.value; }
 }
 
-__global__ __launch_bounds__(1024) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
-                                                               ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
-                                                               const ChainState *st, TraceOut *out) {
-    __shared__ int s_shet, s_ne;
-    if (threadIdx.x == 0) { s_shet = 0; s_ne = 0; }
-    __syncthreads();
+// levels in parallel over the whole grid; *out is zeroed by the host before the launch (value is written by block 0)
+__global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
+                                                              ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
+                                                              const ChainState *st, TraceOut *out) {
     const int value = st->value;
-    if (value != NEG_INF && value != CHAIN_CORRUPT) {
-        int shet = 0;
-        for (int l = 1 + (int)threadIdx.x; l < L; l += (int)blockDim.x) {
-            const uint32_t b = path[l];
-            int i = 0, j = 0;                                         // destination cell at level l = predecessor recorded at l+1
-            if (l < L - 1) { const uint32_t nb = path[l + 1]; i = (int)(nb & 0x7FFFu); j = (int)((nb >> 15) & 0x7FFFu); }
-            const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
-            const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
-            const LevelDesc d = descs[l];
-            const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
-            if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
-            const int reps = (l == L - 1) ? 1 : 0;
-            for (int q = 0; q < reps + wu; ++q) {
-                const int e = atomicAdd(&s_ne, 1);
-                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = u1; edges[2 * cap_e + e] = u2; edges[3 * cap_e + e] = 0; }
-            }
-            for (int q = 0; q < reps + wv; ++q) {
-                const int e = atomicAdd(&s_ne, 1);
-                if (e < cap_e) { edges[e] = l; edges[cap_e + e] = v1; edges[2 * cap_e + e] = v2; edges[3 * cap_e + e] = 1; }
-            }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out->value = value;
+    if (value == NEG_INF || value == CHAIN_CORRUPT) return;
+    int shet = 0;
+    for (int l = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x); l < L; l += (int)(gridDim.x * blockDim.x)) {
+        const uint32_t b = path[l];
+        int i = 0, j = 0;                                             // destination cell at level l = predecessor recorded at l+1
+        if (l < L - 1) { const uint32_t nb = path[l + 1]; i = (int)(nb & 0x7FFFu); j = (int)((nb >> 15) & 0x7FFFu); }
+        const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
+        const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
+        const LevelDesc d = descs[l];
+        const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
+        if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
+        const int reps = (l == L - 1) ? 1 : 0;
+        for (int q = 0; q < reps + wu; ++q) {
+            const int e = atomicAdd(&out->n_e, 1);
+            if (e < cap_e) { edges[e] = l; edges[cap_e + e] = u1; edges[2 * cap_e + e] = u2; edges[3 * cap_e + e] = 0; }
         }
-        if (shet) atomicAdd(&s_shet, shet);
+        for (int q = 0; q < reps + wv; ++q) {
+            const int e = atomicAdd(&out->n_e, 1);
+            if (e < cap_e) { edges[e] = l; edges[cap_e + e] = v1; edges[2 * cap_e + e] = v2; edges[3 * cap_e + e] = 1; }
+        }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        TraceOut o;
-        o.value = value; o.s_het = s_shet; o.n_e = s_ne; o.overflow = s_ne > cap_e ? 1 : 0;
-        *out = o;
-    }
+    for (int sft = 32; sft > 0; sft >>= 1) shet += __shfl_down(shet, sft);
+    if ((threadIdx.x & 63) == 0 && shet) atomicAdd(&out->s_het, shet);
 }
 
 void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {   // row records of destination levels [lb, le), at most ~200 MB worth
@@ -194,7 +187,8 @@ void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp
 }
 
 void trace_launch_finish(const DpState &S, hipStream_t s) {
-    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3(1), dim3(1024), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_path.as<uint32_t>(), colour_csr(S), S.cap,
+    (void)hipMemsetAsync(S.d_trace.p, 0, sizeof(TraceOut), s);
+    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3((unsigned)std::min(1024, (S.L + 255) / 256)), dim3(256), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_path.as<uint32_t>(), colour_csr(S), S.cap,
                        S.d_edges.as<int32_t>(), S.d_chain.as<ChainState>(), S.d_trace.as<TraceOut>());
 }
 

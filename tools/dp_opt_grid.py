@@ -12,10 +12,10 @@ for path in sys.argv[2:]:
     ref = None
     for st in settings:
         for k, v in st.items(): ctx.dp_set_option(k, v)
-        best = 1e30
+        best, best_tb, best_tot = 1e30, 1e30, 1e30
         for it in range(3):
             out = ctx.dp_run(); tm = ctx.dp_timing()
             if ref is None: ref = out.key()
             assert out.key() == ref
-            best = min(best, tm.forward_ms)
-        print(f"{os.path.basename(path):16s} {st}: forward {best:.1f} ms ({1e3*best/(g.n_levels-1):.2f} us/level)", flush=True)
+            best = min(best, tm.forward_ms); best_tb = min(best_tb, tm.traceback_ms); best_tot = min(best_tot, tm.total_ms)
+        print(f"{os.path.basename(path):16s} {st}: forward {best:.1f} ms ({1e3*best/(g.n_levels-1):.2f} us/level), traceback {best_tb:.1f} ms, pass {best_tot:.1f} ms", flush=True)
