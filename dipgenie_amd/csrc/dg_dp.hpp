@@ -108,7 +108,7 @@ struct DpState {
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's table construction
     int64_t bp_nt_min_cells = 16384;                    // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
-    int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = by level width)
+    int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])

@@ -121,15 +121,16 @@ struct Run {
 
     // Sweeps destination levels [lb, le).  bp_biased = lattice pointer minus the offset of level lb's first cell
     // (so the kernels keep using the global LevelDesc::bp_off), or nullptr for a value-only pass.
-    // Issuing a level costs the host 3-4.5 us (hipLaunchKernelGGL), the GPU 2-3 us on narrow levels: batches of levels are
-    // captured once into hipGraphs and replayed on later passes over the same resident graph (option graph_batch).
-    // Measured: MHC_4 (3.5 k cells per level) 390 -> 358 ms per sweep, also on the capturing pass; MHC-24 (265 k cells per
-    // level, GPU-bound) 651 -> 658 ms.  -1 picks 1,000-level batches for graphs below 32 k cells per level.
+    // Issuing a level costs the host 2.3-5.4 us (hipLaunchKernelGGL; it varies from run to run on a shared host), the GPU
+    // 2.7-4.2 us: since the sweep's own period came down to ~4.1 us the chain is host-bound as often as not (MHC-24 sweeps of
+    // 596-742 ms with plain launches, pass after pass of one process).  So the levels are captured into hipGraphs of 1,000
+    // launches and replayed: 590.5-593 ms on MHC-24, the capturing pass included, 320 ms on MHC_4 (option graph_batch: 0 =
+    // plain launches, which at their best are 2 % faster).
     // A stream that cannot be captured (e.g. a caller-provided legacy stream) or a failed instantiation switches the
     // context back to plain launches for good; the batch at hand is then issued again, plainly.
     int sweep_range(int lb, int le, uint16_t *bp_biased) {
         X.A.bp = bp_biased; X.F.bp = bp_biased;
-        const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : ((int64_t)(S.cells / (uint64_t)std::max(S.L, 1)) < 32768 ? 1000 : 0);
+        const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : 1000;
         for (int l0 = lb; l0 < le;) {
             const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
             const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, le) : le;

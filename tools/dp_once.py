@@ -8,8 +8,9 @@ ctx = capi.Context(0)
 g = capi.DpGraphArrays.load(sys.argv[1])
 ctx.dp_set_option("fast", int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 if os.environ.get("DG_SYNC_EVERY"): ctx.dp_set_option("sync_every", int(os.environ["DG_SYNC_EVERY"]))
+if os.environ.get("DG_GRAPH_BATCH"): ctx.dp_set_option("graph_batch", int(os.environ["DG_GRAPH_BATCH"]))
 ctx.dp_load_graph(g)
-for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     out = ctx.dp_run()
-tm = ctx.dp_timing()
-print("value", out.value, "fwd_ms", tm.forward_ms, "tb_ms", tm.traceback_ms)
+    tm = ctx.dp_timing()
+    print("pass", it, "value", out.value, "fwd_ms", round(tm.forward_ms, 1), "tb_ms", round(tm.traceback_ms, 1), flush=True)
