@@ -65,7 +65,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t pad_;
 };
 
-struct TraceOut { int32_t value, s_het, n_e, overflow; };
+struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt; };
 struct ChainState { int32_t i, j, r, value; };
 struct ColourCsr { const int64_t *hom_off, *het_off; const int32_t *hom_col, *het_col; };
 
@@ -111,6 +111,8 @@ struct DpState {
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
+    int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
+    bool lean_chain = false;
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])
     int64_t delta_cap_entries = (int64_t)4 << 30;       // delta_cap_entries: budget of resident score-delta entries
     int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 50;   // rc_*: cost model of the per-level RC choice

@@ -278,7 +278,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
     S.timing.n_forward_launches = run.n_launch;
-    if (to.value == CHAIN_CORRUPT) { set_error("back-pointer lattice is corrupt: the chain walk left its level (a level was not swept?)"); return DG_ERR_STATE; }
+    if (to.value == CHAIN_CORRUPT || to.corrupt) { set_error("back-pointer lattice is corrupt: the chain walk left its level (a level was not swept?)"); return DG_ERR_STATE; }
     if (to.overflow || to.n_e > S.cap) { set_error("traceback edge list overflow (%d > %d)", to.n_e, S.cap); return DG_ERR_STATE; }
     res->value = to.value; res->s_het = to.s_het;
     res->cells = S.cells; res->relaxations = S.relaxations;
@@ -352,7 +352,7 @@ extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
     memcpy(buf, out.c_str(), out.size() + 1);
     return DG_OK;
 }
-// Options: parity / test knobs (digest, fast, adaptive_rc, coop, rowx, segment_cells, delta_cap_entries, lattice_chunk_cells,
+// Options: parity / test knobs (digest, fast, adaptive_rc, coop, rowx, lean_chain, segment_cells, delta_cap_entries, lattice_chunk_cells,
 // graph_batch, warm_ahead), profiler aid (sync_every), tuning (rc_*, bp_nt_min_cells, max_blocks, host_threads).
 extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     if (!c || !key) { dgi::set_error("dg_dp_set_option: null"); return DG_ERR_ARG; }
@@ -361,7 +361,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     dgi::graphs_clear(S);
     struct { const char *name; int64_t *field; int64_t lo; } plain[] = {
         {"digest", &S.want_digest, 0}, {"fast", &S.use_fast, 0}, {"adaptive_rc", &S.adaptive_rc, 0}, {"coop", &S.use_coop, 0},
-        {"rowx", &S.use_rowx, 0},                                  // takes effect at the next load
+        {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1},
         {"host_threads", &S.host_threads, 1},

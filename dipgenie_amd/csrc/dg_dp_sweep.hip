@@ -433,15 +433,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 
 // per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2 [+ 4 per heavy row]), one task per wave (a 3-D
 // grid: splitting a combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
+#ifndef DG_PLAIN_WG
+#define DG_PLAIN_WG 256
+#endif
+#define DG_PLAIN_GW ((DG_PLAIN_WG / 64) < 4 ? (DG_PLAIN_WG / 64) : 4)        // column blocks per workgroup
+#define DG_PLAIN_CH ((DG_PLAIN_WG / 64) / DG_PLAIN_GW)                      // r chunks per workgroup
 template <int RC, bool DIGEST, bool GENERAL>
-__global__ __launch_bounds__(256) void dp_sweep_fast_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
+__global__ __launch_bounds__(DG_PLAIN_WG) void dp_sweep_fast_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
                                                             int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
                                                             FastArgs A, LevelDesc d, int lvl) {
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
-    const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);         // always launched with 4 waves (reading blockDim would be a kernel-argument load)
-    if (g >= nblocks) return;                                           // wave-uniform; no block barrier below
+    const int wv = (int)(threadIdx.x >> 6);
+    const int g = (int)blockIdx.x * DG_PLAIN_GW + (wv % DG_PLAIN_GW);    // always launched with DG_PLAIN_WG threads (reading blockDim would be a kernel-argument load)
+    const int r0 = ((int)blockIdx.y * DG_PLAIN_CH + wv / DG_PLAIN_GW) * RC;
+    if (g >= nblocks || r0 >= (rp_k & 0x1FFF)) return;                  // wave-uniform; no block barrier below
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
-    sweep_task<RC, DIGEST, GENERAL, 0>(H, A, d, state_rsrc(cur, buf_bytes), nxt, (int)blockIdx.z, g, (int)blockIdx.y * RC, lvl);
+    sweep_task<RC, DIGEST, GENERAL, 0>(H, A, d, state_rsrc(cur, buf_bytes), nxt, (int)blockIdx.z, g, r0, lvl);
 }
 
 // the same with a cooperative region: workgroup z < 4 n_heavy = slot block 4 x + (z & 3) of heavy row z >> 2, its four waves
@@ -555,6 +562,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         choose_rc(S, d, l, X.rc_sel, rc, coop);
         const int nch = (S.RP + rc - 1) / rc;
         const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
+        const dim3 pgrid((unsigned)((d.nblocks + DG_PLAIN_GW - 1) / DG_PLAIN_GW), (unsigned)((nch + DG_PLAIN_CH - 1) / DG_PLAIN_CH), grid.z);
         const int32_t *hv = S.d_heavy.as<int32_t>();
         const FastArgs &F = X.F;
         const uint4 *rowrec_l = F.rowrec + d.b0;
@@ -566,8 +574,8 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const int rp_k = S.RP | (d.k << 13);
         unsigned long long hlo = 0, hhi = 0;
         for (int q = 0; q < 4; ++q) { hlo |= (unsigned long long)(uint16_t)d.heavy_in[q] << (16 * q); hhi |= (unsigned long long)(uint16_t)d.heavy_in[4 + q] << (16 * q); }
-#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); \
-                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); } while (0)
+#define DG_FAST(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, true>), pgrid, dim3(DG_PLAIN_WG), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); \
+                              else hipLaunchKernelGGL((dp_sweep_fast_kernel<RCV, DG, false>), pgrid, dim3(DG_PLAIN_WG), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l); } while (0)
 #define DG_COOP(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_coop_kernel<RCV, DG, true>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, d.rowx_stride, d.nblocks, d.n_heavy, rp_k, hlo, hhi, F, d, l, dm, dT, hv); \
                               else hipLaunchKernelGGL((dp_sweep_coop_kernel<RCV, DG, false>), grid, dim3(256), 0, s, rowrec_l, slots_l, rowx_l, cur, d.rowx_stride, d.nblocks, d.n_heavy, rp_k, hlo, hhi, F, d, l, dm, dT, hv); } while (0)
 #define DG_FAST_RC(DG) do { if (coop) { switch (rc) { case 1: DG_COOP(1, DG); break; case 2: DG_COOP(2, DG); break; case 3: DG_COOP(3, DG); break; \

@@ -341,6 +341,12 @@ int Builder::build_level_tables() {
         S.colour_entries += P.colour_entries;
     }
     S.total_units = b_units[NT];
+    {   // the lean chain walk (dg_dp_trace.hip) addresses a level with 32-bit offsets and 24-bit multiplies
+        int kmax = 1;
+        bool wide = false;
+        for (int l = 1; l < L; ++l) { kmax = std::max(kmax, S.descs[l].k2); wide |= S.descs[l].bp_wide != 0; }
+        S.lean_chain = S.use_lean_chain && !wide && S.max_level_cells < ((int64_t)1 << 30) && (int64_t)S.RP * kmax < ((int64_t)1 << 24) && nV < (1 << 27);
+    }
     S.cells = (uint64_t)b_cells[NT];
     S.delta_entries = b_delta[NT];
     S.n_delta_blocks = b_blk[NT];
@@ -561,7 +567,7 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
     S.cap = 2 * (R + 8);                               // edge records of both paths
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
-    if (int rc = S.d_path.ensure(4 * (size_t)L)) return rc;
+    if (int rc = S.d_path.ensure(8 * (size_t)L)) return rc;
     DG_HIP(hipStreamSynchronize(s));      // host staging vectors die here
     lap("allocs + sync");
     for (auto &e : S.ev) if (!e) DG_HIP(hipEventCreate(&e));

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc
                                                                  const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
                                                                  const int32_t *__restrict__ final_val /* non-null on the first call */,
                                                                  const uint4 *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
-                                                                 uint32_t *__restrict__ path, ChainState *st) {
+                                                                 uint2 *__restrict__ path, ChainState *st) {
     const int lane = threadIdx.x & 63;
     ChainWalk W;
     W.csel = 0;
@@ -138,14 +138,140 @@ __global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc
 #undef DG_CHAIN_STOP
 #undef DG_CHAIN_STEP
 #undef DG_DESC
-            if (lane < n && W.value != CHAIN_CORRUPT) path[base - lane] = hops;
+            if (lane < n && W.value != CHAIN_CORRUPT)               // the path holds in-edge style words: source | weight << 31
+                path[base - lane] = make_uint2((hops & 0x7FFFu) | (((hops >> 30) & 1u) << 31), ((hops >> 15) & 0x7FFFu) | ((hops >> 31) << 31));
         }
     }
     if (lane == 0) { st->i = W.i; st->j = W.j; st->r = W.r; st->value = W.value; }
 }
 
+
+// Lean chain walk: the same speculation, for lattices without wide levels whose per-level offsets fit 32 bits (every
+// graph the fast sweep takes).  One wave issues one instruction every four cycles whatever its kind, and the step above
+// costs ~250 of them (0.5 us) -- more than the two overlapped HBM round trips it hides.  This one is written around the
+// instruction count (~1/3): 16-bit loads of the back-pointer itself (no word/parity selection), 24-bit multiply-adds on
+// clamped candidate coordinates instead of selects between "candidate" and "fallback" address sets (a clamped address
+// is always inside the level's block, whatever the lattice holds), scalar-base + 32-bit-offset addressing, the source
+// words parked unpacked, and no per-step validity checks: a back-pointer rank beyond the in-degree reads the all-ones
+// guard word, whose source id is out of range at every level, and the finish kernel (all levels in parallel) checks
+// every hop's source ids against its level's width.
+struct LeanRegs { uint4 row, col; uint32_t b; };
+
+__device__ __forceinline__ void lean_issue(LeanRegs &Y, const uint16_t *__restrict__ bp_level /* wave-uniform: first unit of the level */, const char *__restrict__ rowrec, uint32_t b0, uint32_t k2,
+                                           uint32_t rp_k2, uint32_t ci, uint32_t cj, uint32_t cr) {
+    const uint32_t off = __umul24(ci, rp_k2) + __umul24(cr, k2) + cj;
+    Y.row = *(const uint4 *)(rowrec + ((b0 + ci) << 4));
+    Y.col = *(const uint4 *)(rowrec + ((b0 + cj) << 4));
+    Y.b = *(const uint16_t *)((const char *)bp_level + (off << 1));
+}
+
+struct LeanDesc { const uint16_t *bp_level; uint32_t k2, b0; };
+struct LeanWalk { int r, cs; uint32_t pu, pv; bool bad; };
+
+__device__ __forceinline__ void lean_step(LeanWalk &W, int RP, const LeanDesc &N, const char *rowrec, const uint32_t *__restrict__ in_edge,
+                                          uint32_t &park_u, uint32_t &park_v, int slot, int lane, LeanRegs &X, LeanRegs &Y) {
+    const int cs = __builtin_amdgcn_readfirstlane(W.cs);
+    // guard: rank 1 of a vertex with a single in-edge is not a predecessor
+    const uint32_t xw = X.row.y > 1u ? X.row.w : 0xFFFFFFFFu, yw = X.col.y > 1u ? X.col.w : 0xFFFFFFFFu;
+    const uint32_t riz = (uint32_t)__builtin_amdgcn_readlane((int)X.row.z, cs), riw = (uint32_t)__builtin_amdgcn_readlane((int)xw, cs);
+    const uint32_t rjz = (uint32_t)__builtin_amdgcn_readlane((int)X.col.z, cs), rjw = (uint32_t)__builtin_amdgcn_readlane((int)yw, cs);
+    // one level ahead: this lane's candidate (rank lane&1 of the row, (lane>>1)&1 of the column), clamped into the level
+    const uint32_t wa = (lane & 1) ? riw : riz, wb = (lane & 2) ? rjw : rjz;
+    const uint32_t ci = min(wa & 0x7FFFu, N.k2 - 1u), cj = min(wb & 0x7FFFu, N.k2 - 1u);
+    const uint32_t cr = (uint32_t)max(W.r - (int)(wa >> 31) - (int)(wb >> 31), 0);
+    lean_issue(Y, N.bp_level, rowrec, N.b0, N.k2, (uint32_t)RP * N.k2, ci, cj, cr);
+    // the candidates' loads are issued HERE, before this level's back-pointer (issued one step ago) is waited for
+    // (the broadcast is spelled out so that it -- and the wait in front of it -- cannot be scheduled above the loads; cs is written
+    // by scalar instructions only, so the VALU-writes-lane-select hazard does not apply)
+    uint32_t bv;
+    asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(bv) : "v"(X.b), "s"(cs) : "memory");
+    const uint32_t eu = bv >> 8, ev = bv & 0xFFu;
+    uint32_t pu, pv;
+    if ((eu | ev) > 1u) {                                               // rare: a rank above 1 (or 0xFFFF = unreachable)
+        const uint32_t rix = (uint32_t)__builtin_amdgcn_readlane((int)X.row.x, cs), riy = (uint32_t)__builtin_amdgcn_readlane((int)X.row.y, cs);
+        const uint32_t rjx = (uint32_t)__builtin_amdgcn_readlane((int)X.col.x, cs), rjy = (uint32_t)__builtin_amdgcn_readlane((int)X.col.y, cs);
+        if (eu >= riy || ev >= rjy) { W.bad = true; pu = pv = 0; }
+        else {
+            pu = eu == 0 ? riz : (eu == 1 ? riw : in_edge[rix + eu]);
+            pv = ev == 0 ? rjz : (ev == 1 ? rjw : in_edge[rjx + ev]);
+            pu = (uint32_t)__builtin_amdgcn_readfirstlane((int)pu); pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv);
+        }
+        W.r -= (int)(pu >> 31) + (int)(pv >> 31);
+        // exact loads of the predecessor replace the candidates in flight.  (The candidates are "used" here so that the
+        // compiler cannot treat their loads as dead on this path and sink the issue below the branch -- behind the wait.)
+        asm volatile("" :: "v"(Y.b), "v"(Y.row.x), "v"(Y.col.x));
+        uint32_t ei = min(pu & 0x7FFFu, N.k2 - 1u), ej = min(pv & 0x7FFFu, N.k2 - 1u);
+        asm volatile("" : "+v"(ei), "+v"(ej));                          // vector loads like the candidates' (same registers, same extension)
+        lean_issue(Y, N.bp_level, rowrec, N.b0, N.k2, (uint32_t)RP * N.k2, ei, ej, (uint32_t)max(W.r, 0));
+        W.cs = 0;
+    } else {
+        pu = eu ? riw : riz;
+        pv = ev ? rjw : rjz;
+        W.r -= (int)(pu >> 31) + (int)(pv >> 31);
+        W.cs = (int)(eu | (ev << 1));
+    }
+    W.pu = pu; W.pv = pv;
+    park_u = lane == slot ? pu : park_u;                                // lane t keeps the t-th level's words: one store per batch
+    park_v = lane == slot ? pv : park_v;
+}
+
+__global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
+                                                                 const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
+                                                                 const int32_t *__restrict__ final_val /* non-null on the first call */,
+                                                                 const uint4 *__restrict__ rowrec_, const uint32_t *__restrict__ in_edge,
+                                                                 uint2 *__restrict__ path, ChainState *st) {
+    const int lane = threadIdx.x & 63;
+    const char *rowrec = (const char *)rowrec_;
+    int value, si, sj;
+    LeanWalk W;
+    W.cs = 0; W.bad = false; W.pu = W.pv = 0;
+    if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; si = 0; sj = 0; W.r = R; }       // sink level, layout [i][r][j]: cell (0, R, 0)
+    else { si = st->i; sj = st->j; W.r = st->r; value = st->value; }
+    if (value != NEG_INF && value != CHAIN_CORRUPT) {
+        LeanRegs A, B;
+        bool first = true;
+        for (int base = l_hi; base >= l_lo && !W.bad; base -= 56) {
+            const int my_l = max(base - lane, l_lo);                   // 64 descriptors, 56 levels (a multiple of 8) per batch; the range's
+            const LevelDesc &dd = descs[my_l];                          // first level stands in for what lies below it (clamped loads only)
+            const int64_t ba = dd.bp_off * 2;                           // byte offset of the level's first unit from the biased base
+            int ba_lo = (int)ba, ba_hi = (int)(ba >> 32), kk = dd.k2, bb = dd.b0;
+            asm volatile("" ::"v"(ba_lo), "v"(ba_hi), "v"(kk), "v"(bb)); // descriptors complete before the walk (no wait inside the loop)
+            const int n = min(56, base - l_lo + 1);
+            uint32_t park_u = 0, park_v = 0;
+#define DG_DESC(T) LeanDesc{(const uint16_t *)((const char *)bp + (((int64_t)__builtin_amdgcn_readlane(ba_hi, (T)) << 32) | (uint32_t)__builtin_amdgcn_readlane(ba_lo, (T)))), \
+                           (uint32_t)__builtin_amdgcn_readlane(kk, (T)), (uint32_t)__builtin_amdgcn_readlane(bb, (T))}
+            if (first) {                                                // prologue: exact loads of the starting cell
+                const LeanDesc D0 = DG_DESC(0);
+                lean_issue(A, D0.bp_level, rowrec, D0.b0, D0.k2, (uint32_t)RP * D0.k2, min((uint32_t)si, D0.k2 - 1u), min((uint32_t)sj, D0.k2 - 1u), (uint32_t)max(W.r, 0));
+                first = false;
+            }
+            // unrolled by hand (8 steps per trip): the loop's back edge copies the registers of the loads in flight, and so
+            // waits for them -- one un-overlapped step per trip
+#define DG_LEAN_STEP(T, X, Y) { const LeanDesc DN = DG_DESC((T) + 1); lean_step(W, RP, DN, rowrec, in_edge, park_u, park_v, (T), lane, X, Y); }
+#define DG_LEAN_STOP(T) (W.bad || (T) >= n)
+            for (int t = 0; t < n; t += 8) {
+                DG_LEAN_STEP(t, A, B);     if (DG_LEAN_STOP(t + 1)) break;
+                DG_LEAN_STEP(t + 1, B, A); if (DG_LEAN_STOP(t + 2)) break;
+                DG_LEAN_STEP(t + 2, A, B); if (DG_LEAN_STOP(t + 3)) break;
+                DG_LEAN_STEP(t + 3, B, A); if (DG_LEAN_STOP(t + 4)) break;
+                DG_LEAN_STEP(t + 4, A, B); if (DG_LEAN_STOP(t + 5)) break;
+                DG_LEAN_STEP(t + 5, B, A); if (DG_LEAN_STOP(t + 6)) break;
+                DG_LEAN_STEP(t + 6, A, B); if (DG_LEAN_STOP(t + 7)) break;
+                DG_LEAN_STEP(t + 7, B, A); if (DG_LEAN_STOP(t + 8)) break;
+            }
+#undef DG_LEAN_STOP
+#undef DG_LEAN_STEP
+#undef DG_DESC
+            if (lane < n && !W.bad) path[base - lane] = make_uint2(park_u, park_v);
+            si = (int)(W.pu & 0x7FFFu); sj = (int)(W.pv & 0x7FFFu);
+        }
+        if (W.bad || W.r < 0) value = CHAIN_CORRUPT;
+    }
+    if (lane == 0) { st->i = si; st->j = sj; st->r = W.r; st->value = value; }
+}
+
 // levels in parallel over the whole grid; *out is zeroed by the host before the launch (value is written by block 0)
-__global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint32_t *__restrict__ path,
+__global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint2 *__restrict__ path,
                                                               ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
                                                               const ChainState *st, TraceOut *out) {
     const int value = st->value;
@@ -153,12 +279,13 @@ __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *_
     if (value == NEG_INF || value == CHAIN_CORRUPT) return;
     int shet = 0;
     for (int l = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x); l < L; l += (int)(gridDim.x * blockDim.x)) {
-        const uint32_t b = path[l];
+        const uint2 b = path[l];
         int i = 0, j = 0;                                             // destination cell at level l = predecessor recorded at l+1
-        if (l < L - 1) { const uint32_t nb = path[l + 1]; i = (int)(nb & 0x7FFFu); j = (int)((nb >> 15) & 0x7FFFu); }
-        const int pi = (int)(b & 0x7FFFu), pj = (int)((b >> 15) & 0x7FFFu);
-        const int wu = (int)((b >> 30) & 1u), wv = (int)(b >> 31);
+        if (l < L - 1) { const uint2 nb = path[l + 1]; i = (int)(nb.x & 0x7FFFu); j = (int)(nb.y & 0x7FFFu); }
+        const int pi = (int)(b.x & 0x7FFFu), pj = (int)(b.y & 0x7FFFu);
+        const int wu = (int)(b.x >> 31), wv = (int)(b.y >> 31);
         const LevelDesc d = descs[l];
+        if (pi >= d.k || pj >= d.k) { out->corrupt = 1; continue; }  // a hop that leaves its source level (the lean walk does not check per step)
         const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
         if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
         const int reps = (l == L - 1) ? 1 : 0;
@@ -182,13 +309,17 @@ void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {  
 }
 
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s) {
-    hipLaunchKernelGGL(dp_trace_chain_spec_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
-                       S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint32_t>(), S.d_chain.as<ChainState>());
+    if (S.lean_chain)
+        hipLaunchKernelGGL(dp_trace_chain_lean_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
+                           S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>());
+    else
+        hipLaunchKernelGGL(dp_trace_chain_spec_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
+                           S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>());
 }
 
 void trace_launch_finish(const DpState &S, hipStream_t s) {
     (void)hipMemsetAsync(S.d_trace.p, 0, sizeof(TraceOut), s);
-    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3((unsigned)std::min(1024, (S.L + 255) / 256)), dim3(256), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_path.as<uint32_t>(), colour_csr(S), S.cap,
+    hipLaunchKernelGGL(dp_trace_finish_kernel, dim3((unsigned)std::min(1024, (S.L + 255) / 256)), dim3(256), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_path.as<uint2>(), colour_csr(S), S.cap,
                        S.d_edges.as<int32_t>(), S.d_chain.as<ChainState>(), S.d_trace.as<TraceOut>());
 }
 
