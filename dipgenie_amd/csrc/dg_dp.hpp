@@ -113,6 +113,7 @@ struct DpState {
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
     int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
     bool lean_chain = false;
+    mutable int chain_seq = 0;                          // per-launch number of the lean chain walk (ChainSync, dg_dp_trace.hip)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])
     int64_t delta_cap_entries = (int64_t)4 << 30;       // delta_cap_entries: budget of resident score-delta entries
     int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 50;   // rc_*: cost model of the per-level RC choice
@@ -207,5 +208,6 @@ void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, h
 void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s);
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s);
 void trace_launch_finish(const DpState &S, hipStream_t s);
+void trace_debug_report(const DpState &S);
 
 }  // namespace dgi

@@ -270,6 +270,7 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         if (FILE *f = fopen(po, "wb")) { fwrite(pr.data(), 8, pr.size(), f); fclose(f); }
     }
 #endif
+    if (getenv("DG_DEBUG") && S.lean_chain) trace_debug_report(S);
     if (getenv("DG_DEBUG"))
         fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)run.n_launch, 1e3 * run.host_enqueue_s,
                 1e6 * run.host_enqueue_s / (double)std::max<int64_t>(run.n_launch, 1));

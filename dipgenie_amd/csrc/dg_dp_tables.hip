@@ -552,7 +552,8 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
-    if (int rc = S.d_chain.ensure(sizeof(ChainState))) return rc;
+    if (int rc = S.d_chain.ensure(128)) return rc;                 // ChainState, and ChainSync at +64
+    DG_HIP(hipMemsetAsync(S.d_chain.p, 0, 128, s)); S.chain_seq = 0;
     S.pad_front = 2 * (int64_t)B.max_k;
     const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)B.max_k);
     if (int rc = S.d_val[0].ensure(st_bytes / 2 + pad_bytes)) return rc;

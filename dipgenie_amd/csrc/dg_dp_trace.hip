@@ -215,18 +215,109 @@ __device__ __forceinline__ void lean_step(LeanWalk &W, int RP, const LeanDesc &N
     park_v = lane == slot ? pv : park_v;
 }
 
+// Prefetch workgroups.  With ~90 instructions per level the walk is bound by memory latency: the HBM round trip of its
+// back-pointer load (two in flight) and the row-record load that leads to the next candidates (~0.34 us per level).  The
+// walker cannot know its cell any earlier, but r only ever decreases along the walk, and rarely: the cell of a level
+// some tens of levels down lies in plane r or r - 1 of that level, 2 * k2 rows of k2 back-pointers -- 16 KB on a 64-wide
+// level.  Helper workgroups ON THE WALKER'S XCD (the L2 is per XCD; a helper wave on the walker's own CU was measured
+// and is worse than none: 80 vs 54 ms, its misses queue in front of the walker's loads in the CU's in-order memory
+// pipeline) read those planes, one load per 128-byte line with the data dropped, and the level's row records, keeping
+// up to LEAN_AHEAD_MAX levels ahead of the position the walker publishes every eight levels; the walker's loads then
+// hit the L2.  A wrong guess (a third recombination inside the window) costs an ordinary miss, nothing else.
+// Protocol (ChainSync, in global memory; relaxed agent-scope atomics -- hints, nothing depends on their order): the
+// walker (block 0) publishes its XCC id and seq << 32 | level; every other block of the launch whose XCC id matches
+// takes a ticket, the first LEAN_PREFETCHERS tickets prefetch, everybody else leaves.  seq (a per-launch number) keeps a
+// helper from acting on the previous launch's words; whatever it reads, it only ever touches levels of [l_lo, l_hi].
+constexpr int LEAN_AHEAD_MAX = 96, LEAN_AHEAD_BYTES = 3 << 19;      // window: at most 96 levels and ~1.5 MB of planes
+constexpr int LEAN_PREFETCHERS = 8, LEAN_BLOCKS = 80, LEAN_POLL_EVERY = 4;
+struct ChainSync { unsigned long long pos; int r, xcc; int ticket[2]; int n_helpers, n_levels; };   // (the last two: DG_DEBUG statistics)
+
+__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20); }   // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ void lean_prefetch(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, const uint16_t *__restrict__ bp,
+                                              const char *__restrict__ rowrec, ChainSync *sy, int seq, int *dump /* LDS, 64 words */, int lane) {
+    // a load whose data nobody wants: straight into an LDS dump word per lane -- no destination register that a later value
+    // could be sharing when the data arrives, nothing to wait for
+#define DG_DROP_LOAD(PTR) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(PTR), (__attribute__((address_space(3))) void *)dump, 4, 0, 0)
+    unsigned long long pos;
+    int spins = 0;
+    do {                                                                // the walker's first words of THIS launch
+        pos = __hip_atomic_load(&sy->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(pos >> 32) != seq) { __builtin_amdgcn_s_sleep(32); if (++spins > (1 << 20)) return; }
+    } while ((int)(pos >> 32) != seq);
+    if ((int)(uint32_t)pos == INT32_MIN) return;
+    if (__hip_atomic_load(&sy->xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id()) return;
+    int me = 0;
+    if (lane == 0) me = atomicAdd(&sy->ticket[seq & 1], 1);
+    me = __builtin_amdgcn_readfirstlane(me);
+    if (me >= LEAN_PREFETCHERS) return;
+    // this block's levels: l_hi - me - LEAN_PREFETCHERS * q.  Their descriptors are fetched 64 at a time, one per lane, so that no
+    // level waits for a dependent descriptor load of its own; the position is polled every LEAN_POLL_EVERY levels (an L2 round trip)
+    int done = 0, lw = l_hi, rw = RP - 1;
+    bool live = true;
+    for (int lp = l_hi - me; live && lp >= l_lo; lp -= LEAN_PREFETCHERS * 64) {
+        const int my_l = max(lp - LEAN_PREFETCHERS * lane, l_lo);
+        const LevelDesc &dd = descs[my_l];
+        const int64_t bo = dd.bp_off * 2;
+        int bo_lo = (int)bo, bo_hi = (int)(bo >> 32), kk = dd.k2, bb = dd.b0;
+        for (int j = 0; j < 64 && live; ++j) {
+            const int l = lp - LEAN_PREFETCHERS * j;
+            if (l < l_lo) break;
+            const int k2 = __builtin_amdgcn_readlane(kk, j), b0 = __builtin_amdgcn_readlane(bb, j);
+            const char *lvl = (const char *)bp + (((int64_t)__builtin_amdgcn_readlane(bo_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(bo_lo, j));
+            const int ahead = max(8, min(LEAN_AHEAD_MAX, LEAN_AHEAD_BYTES / (4 * k2 * k2)));
+            for (bool first = true; live; first = false) {              // fresh position: every few levels, and while too far ahead
+                if (!first || j % LEAN_POLL_EVERY == 0) {
+                    pos = __hip_atomic_load(&sy->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    lw = __builtin_amdgcn_readfirstlane((int)(uint32_t)pos);
+                    rw = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sy->r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (lw == INT32_MIN || (int)(pos >> 32) != seq) live = false;
+                }
+                if (!live || lw - l <= ahead) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!live) break;
+            if (l > lw) continue;                                       // overtaken
+            const int r_hi = min(max(rw, 0), RP - 1);
+            const int row_bytes = 2 * k2, lines = (row_bytes + 127) >> 7;   // 128-byte lines of one (i, r) row of back-pointers
+            const int n = 2 * k2 * lines;
+            for (int t = lane; t < n; t += 64) {
+                const int ln = t % lines, q = t / lines, i = q >> 1, r = max(r_hi - (q & 1), 0);
+                const uint32_t off = (uint32_t)(((uint32_t)i * (uint32_t)RP + (uint32_t)r) * (uint32_t)k2) * 2u + (uint32_t)min(ln << 7, row_bytes - 2);
+                DG_DROP_LOAD(lvl + (off & ~3u));
+            }
+            for (int t = lane; t < ((k2 * 16 + 127) >> 7); t += 64) {
+                const uint32_t off = ((uint32_t)b0 << 4) + (uint32_t)min(t << 7, k2 * 16 - 4);
+                DG_DROP_LOAD(rowrec + off);
+            }
+            ++done;
+        }
+    }
+    if (lane == 0) { atomicAdd(&sy->n_helpers, 1); atomicAdd(&sy->n_levels, done); }
+#undef DG_DROP_LOAD
+}
+
 __global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
                                                                  const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
                                                                  const int32_t *__restrict__ final_val /* non-null on the first call */,
                                                                  const uint4 *__restrict__ rowrec_, const uint32_t *__restrict__ in_edge,
-                                                                 uint2 *__restrict__ path, ChainState *st) {
+                                                                 uint2 *__restrict__ path, ChainState *st, ChainSync *sy, int seq) {
+    __shared__ int dump_s[64];
     const int lane = threadIdx.x & 63;
     const char *rowrec = (const char *)rowrec_;
+    if (blockIdx.x != 0) { lean_prefetch(descs, l_hi, l_lo, RP, bp, rowrec, sy, seq, dump_s, lane); return; }
     int value, si, sj;
     LeanWalk W;
     W.cs = 0; W.bad = false; W.pu = W.pv = 0;
     if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; si = 0; sj = 0; W.r = R; }       // sink level, layout [i][r][j]: cell (0, R, 0)
     else { si = st->i; sj = st->j; W.r = st->r; value = st->value; }
+#define DG_PUBLISH(LV, RV) do { __hip_atomic_store(&sy->r, (RV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                                __hip_atomic_store(&sy->pos, ((unsigned long long)(uint32_t)seq << 32) | (uint32_t)(LV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    if (lane == 0) {
+        __hip_atomic_store(&sy->ticket[(seq + 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the next launch's counter
+        __hip_atomic_store(&sy->xcc, xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DG_PUBLISH((value != NEG_INF && value != CHAIN_CORRUPT) ? l_hi : INT32_MIN, W.r);
+    }
     if (value != NEG_INF && value != CHAIN_CORRUPT) {
         LeanRegs A, B;
         bool first = true;
@@ -250,6 +341,7 @@ __global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc
 #define DG_LEAN_STEP(T, X, Y) { const LeanDesc DN = DG_DESC((T) + 1); lean_step(W, RP, DN, rowrec, in_edge, park_u, park_v, (T), lane, X, Y); }
 #define DG_LEAN_STOP(T) (W.bad || (T) >= n)
             for (int t = 0; t < n; t += 8) {
+                if (lane == 0) DG_PUBLISH(base - t, W.r);
                 DG_LEAN_STEP(t, A, B);     if (DG_LEAN_STOP(t + 1)) break;
                 DG_LEAN_STEP(t + 1, B, A); if (DG_LEAN_STOP(t + 2)) break;
                 DG_LEAN_STEP(t + 2, A, B); if (DG_LEAN_STOP(t + 3)) break;
@@ -267,7 +359,8 @@ __global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc
         }
         if (W.bad || W.r < 0) value = CHAIN_CORRUPT;
     }
-    if (lane == 0) { st->i = si; st->j = sj; st->r = W.r; st->value = value; }
+    if (lane == 0) { DG_PUBLISH(INT32_MIN, 0); st->i = si; st->j = sj; st->r = W.r; st->value = value; }
+#undef DG_PUBLISH
 }
 
 // levels in parallel over the whole grid; *out is zeroed by the host before the launch (value is written by block 0)
@@ -310,11 +403,18 @@ void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {  
 
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s) {
     if (S.lean_chain)
-        hipLaunchKernelGGL(dp_trace_chain_lean_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
-                           S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>());
+        hipLaunchKernelGGL(dp_trace_chain_lean_kernel, dim3(LEAN_BLOCKS), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
+                           S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>(),
+                           (ChainSync *)(S.d_chain.as<char>() + 64), ++S.chain_seq);
     else
         hipLaunchKernelGGL(dp_trace_chain_spec_kernel, dim3(1), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
                            S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>());
+}
+
+void trace_debug_report(const DpState &S) {                            // DG_DEBUG: how much of the walk the helpers covered
+    ChainSync sy;
+    if (hipMemcpy(&sy, S.d_chain.as<char>() + 64, sizeof sy, hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[dg] chain walk helpers: %d block-launches prefetched %d levels (since load)\n", sy.n_helpers, sy.n_levels);
 }
 
 void trace_launch_finish(const DpState &S, hipStream_t s) {
