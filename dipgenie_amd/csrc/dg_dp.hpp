@@ -124,6 +124,7 @@ struct DpState {
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     bool graph_failed = false;                          // capture or instantiation failed once: plain launches from then on
     std::map<std::tuple<int, int, const void *>, hipGraphExec_t> graphs;   // (first level, end level, biased lattice pointer) -> replayable batch
+    std::map<std::tuple<int, int, const void *>, std::vector<int64_t>> graph_hist;   // ... -> its launches by kernel variant (launch_hist)
     bool all_fast = false;
     size_t state_alloc_bytes = 0;
     std::vector<LevelDesc> descs;

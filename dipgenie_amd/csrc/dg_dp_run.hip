@@ -15,6 +15,7 @@ double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); retur
 void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
     for (auto &kv : S.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
     S.graphs.clear();
+    S.graph_hist.clear();
 }
 
 void dp_state_free(DpState *s) {
@@ -137,12 +138,20 @@ struct Run {
             hipGraphExec_t *slot = nullptr;
             bool capturing = false;
             if (use_graph) {
-                slot = &S.graphs[std::make_tuple(l0, l1, (const void *)bp_biased)];
-                if (*slot) { DG_HIP(hipGraphLaunch(*slot, s)); n_launch += l1 - l0; l0 = l1; continue; }
+                const auto key = std::make_tuple(l0, l1, (const void *)bp_biased);
+                slot = &S.graphs[key];
+                if (*slot) {
+                    DG_HIP(hipGraphLaunch(*slot, s));
+                    const std::vector<int64_t> &h = S.graph_hist[key];
+                    for (size_t q = 0; q < h.size(); ++q) S.launch_hist[q] += h[q];
+                    n_launch += l1 - l0; l0 = l1;
+                    continue;
+                }
                 if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
                 else { (void)hipGetLastError(); S.graph_failed = true; continue; }
             }
             const int64_t n_launch_before = n_launch;
+            std::vector<int64_t> hist_before(S.launch_hist, S.launch_hist + 64 * 4);
             if (int rc = issue_levels(l0, l1, lb, le)) return rc;
             if (capturing) {
                 hipGraph_t cg = nullptr;
@@ -151,8 +160,12 @@ struct Run {
                 if (!ok) {                                          // nothing of this batch has run: issue it again without a graph
                     (void)hipGetLastError();
                     *slot = nullptr; S.graph_failed = true; n_launch = n_launch_before;
+                    std::copy(hist_before.begin(), hist_before.end(), S.launch_hist);
                     continue;
                 }
+                std::vector<int64_t> &h = S.graph_hist[std::make_tuple(l0, l1, (const void *)bp_biased)];
+                h.resize(64 * 4);
+                for (size_t q = 0; q < h.size(); ++q) h[q] = S.launch_hist[q] - hist_before[q];
                 DG_HIP(hipGraphLaunch(*slot, s));
             }
             l0 = l1;

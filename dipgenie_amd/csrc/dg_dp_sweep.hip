@@ -560,6 +560,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         int rc;
         bool coop;
         choose_rc(S, d, l, X.rc_sel, rc, coop);
+        S.launch_hist[(rc & 63) * 4 + (d.fast_ok == 2 ? 2 : 0) + (coop ? 1 : 0)]++;
         const int nch = (S.RP + rc - 1) / rc;
         const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
         const dim3 pgrid((unsigned)((d.nblocks + DG_PLAIN_GW - 1) / DG_PLAIN_GW), (unsigned)((nch + DG_PLAIN_CH - 1) / DG_PLAIN_CH), grid.z);

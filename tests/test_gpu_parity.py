@@ -155,6 +155,24 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             gpu_ctx.dp_set_option(k, v)
 
 
+def test_dp_launch_profile_counts_every_level(gpu_ctx):
+    """dg_dp_get_launch_profile (what bench.py matches its rocprof summary against): one launch per destination level,
+    the same on a replayed pass (hipGraph batches) as on the capturing one, and with plain launches"""
+    g = graphgen.random_levelized(7400, max_width=20, n_levels=2500, R=6, p_w1=0.4)
+    gpu_ctx.dp_load_graph(g)
+    profiles = []
+    for _ in range(3):
+        gpu_ctx.dp_run()
+        profiles.append(gpu_ctx.dp_launch_profile())
+    assert sum(profiles[0].values()) == g.n_levels - 1 and profiles[0] == profiles[1] == profiles[2], profiles
+    try:
+        gpu_ctx.dp_set_option("graph_batch", 0)
+        gpu_ctx.dp_run()
+        assert gpu_ctx.dp_launch_profile() == profiles[0]
+    finally:
+        gpu_ctx.dp_set_option("graph_batch", -1)
+
+
 def test_dp_large_recombination_budget(gpu_ctx):
     """R >= 1024 (the level-0 initialisation used to be one over-sized block): values, edge lists and digests"""
     _dp_both(gpu_ctx, graphgen.random_levelized(7300, max_width=5, n_levels=12, R=1100, p_w1=0.5))
