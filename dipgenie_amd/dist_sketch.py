@@ -106,8 +106,11 @@ class Score:
 class ShardedSketch:
     """One instance per rank.  `ops`: HipOps (product) or a test shim with the same methods."""
 
-    def __init__(self, ops, device):
-        self.ops, self.device = ops, device
+    def __init__(self, ops, device, force_exchange=False):
+        """force_exchange: take the collective path even in a world of one rank (tools/rccl_rehearsal.py: every RCCL call
+        of the sharded path exercised on a single GPU)"""
+        self.ops, self.device, self.force_exchange = ops, device, force_exchange
+        self.laps = None                                 # tools/rccl_rehearsal.py: dict of per-stage seconds (synchronising, so not for timed runs)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.gloo = dist.is_initialized() and dist.get_backend() == "gloo"
@@ -133,45 +136,68 @@ class ShardedSketch:
         caller.wait_stream(self.stream)
         return out
 
+    def _lap(self, name):
+        if self.laps is not None:
+            import time
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.laps[name] = self.laps.get(name, 0.0) + now - self._t
+            self._t = now
+
     def _score(self, bases_t, off_t, dict_t, k, w):
         ops, W, me = self.ops, self.world, self.rank
+        if self.laps is not None:
+            import time
+            torch.cuda.synchronize(); self._t = time.perf_counter()
         h, c = ops.sketch_reads(bases_t, off_t, k, w)
+        self._lap("sketch")
         counts = ops.count_dictionary(dict_t, h, c)
+        self._lap("count_dictionary")
         work = None
-        if W > 1:                                        # (1) hit vector: asynchronous, overlaps the exchange
+        multi = W > 1 or (self.force_exchange and dist.is_initialized())
+        if multi:                                        # (1) hit vector: asynchronous, overlaps the exchange
             counts_c = self._c(counts)
             work = dist.all_reduce(counts_c, op=dist.ReduceOp.SUM, async_op=True)
-        if W == 1:
+            self._lap("all_reduce counts (issue)")
+        if not multi:
             rh, rc = h, c
         else:                                            # (2) hash-range exchange
             split = ops.partition(h, W)
+            self._lap("partition")
             send = self._c((split[1:] - split[:-1]).contiguous())
             mat = torch.empty(W * W, dtype=torch.int64, device=send.device)
             dist.all_gather_into_tensor(mat, send)       # world x world send-count matrix: the one size exchange
             mat = mat.view(W, W).cpu()                   # the one host read of the exchange
             in_splits, out_splits = mat[me].tolist(), mat[:, me].tolist()
+            self._lap("all_gather counts + host read")
             payload = self._c(torch.stack([h, c.to(torch.int64)], dim=1).contiguous())     # [n, 2]: one collective for both columns
             recv = torch.empty((sum(out_splits), 2), dtype=torch.int64, device=payload.device)
+            self._lap("pack payload")
             dist.all_to_all_single(recv, payload, output_split_sizes=out_splits, input_split_sizes=in_splits)
             recv = self._back(recv)
+            self._lap("all_to_all")
             rh, rc = ops.merge_runs(recv[:, 0].contiguous(), recv[:, 1].to(torch.int32).contiguous())
+            self._lap("unpack + merge_runs")
         # (3) per-range distinct counts | multiplicity histogram | dictionary ids, one fused all-reduce
         M = dict_t.numel()
         tail = torch.zeros(W + HIST_BINS + M, dtype=torch.int64, device=self.device)
         tail[me] = rh.numel()
         ops.histogram(rc, tail[W: W + HIST_BINS])
         ops.rank_dictionary(dict_t, rh, tail[W + HIST_BINS:])
-        if W > 1:
+        self._lap("histogram + rank_dictionary")
+        if multi:
             tail_c = self._c(tail)
             dist.all_reduce(tail_c, op=dist.ReduceOp.SUM)
             tail = self._back(tail_c)
             work.wait()
             counts = self._back(counts_c)
+            self._lap("fused all_reduce + wait")
         sizes = tail[:W]
         base = torch.cumsum(sizes, 0) - sizes            # exclusive scan: first global id of every range
         rank1 = tail[W + HIST_BINS:]
         ids = torch.where(rank1 > 0, rank1 - 1 + base[hash_owner(dict_t, W)], torch.full_like(rank1, -1))
         sizes_h = sizes.cpu().tolist()
+        self._lap("ids + host read")
         return Score(counts=counts, ids=ids, n_distinct=int(sum(sizes_h)), hist=tail[W: W + HIST_BINS], range_hash=rh, range_count=rc,
                      range_base=int(sum(sizes_h[:me])), range_sizes=sizes_h)
 

@@ -136,3 +136,15 @@ def _shard_exchange_merge(cfg4, world):
     ids = torch.where(r1 > 0, r1 - 1 + torch.tensor(bases)[hash_owner(dict_t.cpu(), world)], torch.full_like(r1, -1)).numpy()
     assert np.array_equal(ids, _join(h1, c1, D)[1])
     assert np.array_equal(hist.cpu().numpy(), np.bincount(np.minimum(c1, HIST_BINS - 1), minlength=HIST_BINS))
+
+
+def test_config4_collective_path_under_rccl_world_of_one(cfg4):
+    """every RCCL call of the sharded class (async all-reduce, all-gather of the send counts, all-to-all of the runs, fused
+    all-reduce) on this GPU: torch.distributed "nccl" backend in a world of one rank, the class forced through its
+    collective path, in a child process (tools/rccl_rehearsal.py asserts equality with the collective-free pass)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_rehearsal.py"), "300000"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b"RCCL world-1 rehearsal OK: 300000 reads" in p.stdout, p.stdout.decode()[-2000:]
