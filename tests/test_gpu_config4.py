@@ -24,8 +24,8 @@ for a, b in zip(b"ACGT", b"TGCA"):
 
 @pytest.fixture(scope="module")
 def cfg4(tmp_path_factory, gpu_ctx):
-    cache = os.environ.get("DG_BENCH_CACHE", str(tmp_path_factory.mktemp("cfg4")))
-    cache = os.path.join(cache, "mhc24")
+    cache_root = os.environ.get("DG_BENCH_CACHE", str(tmp_path_factory.mktemp("cfg4")))
+    cache = os.path.join(cache_root, "mhc24")
     gfa, _, _ = synth.ensure_mhc24(cache)
     arr = np.load(synth.ensure_mhc24_reads(cache), mmap_mode="r")
     assert arr.shape == (1007415, 150)
@@ -34,7 +34,7 @@ def cfg4(tmp_path_factory, gpu_ctx):
     ctx = capi.Context(0)
     dev = torch.device("cuda", 0)
     ops = HipOps(ctx, dev)
-    yield dict(arr=np.array(arr), D=D, ops=ops, dev=dev, dict_t=torch.from_numpy(D.view(np.int64).copy()).to(dev))
+    yield dict(cache_root=cache_root, arr=np.array(arr), D=D, ops=ops, dev=dev, dict_t=torch.from_numpy(D.view(np.int64).copy()).to(dev))
     ctx.close()
 
 
@@ -144,7 +144,7 @@ def test_config4_collective_path_under_rccl_world_of_one(cfg4):
     collective path, in a child process (tools/rccl_rehearsal.py asserts equality with the collective-free pass)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0", DG_BENCH_CACHE=cfg4["cache_root"])
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_rehearsal.py"), "300000"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b"RCCL world-1 rehearsal OK: 300000 reads" in p.stdout, p.stdout.decode()[-2000:]
