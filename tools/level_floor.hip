@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256) void k_persist(int n_iter, const uint32_t *__r
     }
 }
 
+// Chained levels: ONE dispatch covers M levels of G workgroups each; a workgroup of level q does its first (independent)
+// load round, then waits until all G workgroups of level q - 1 have signalled, reads their values with agent-scope loads,
+// stores with agent-scope stores and signals.  Workgroups are dispatched in id order (per XCD), so every workgroup a
+// spinner waits for is already placed or ahead of it in its XCD's queue -- the forward-progress argument of decoupled
+// look-back scans.  Spins are bounded (abort flag).  What it would buy the sweep: the drain of level q overlaps the
+// dispatch ramp and first load round of level q + 1, and there is no release / acquire of whole L2s in between.
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_chain(int G, int level0, const uint32_t *__restrict__ rec, uint32_t *s0, uint32_t *s1, uint32_t mask, uint32_t *done, Ctl *ctl, int cold_stride) {
+    const int q = (int)blockIdx.x / G, w = (int)blockIdx.x % G, lvl = level0 + q;
+    const uint32_t t = (uint32_t)w * 256u + threadIdx.x;
+    const uint32_t *cur = (lvl & 1) ? s1 : s0;
+    uint32_t *nxt = (lvl & 1) ? s0 : s1;
+    uint32_t x = rec[(size_t)(lvl & 4095) * cold_stride + t];
+    if (q > 0) {                                                      // (level0 follows a kernel boundary)
+        if (threadIdx.x == 0) {
+            uint32_t spin = 0;
+            while (__hip_atomic_load(&done[lvl - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)G) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > (1u << 18) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 1; r < ROUNDS; ++r) x = __hip_atomic_load(&cur[(x + (uint32_t)r * 64u) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&nxt[t & mask], (x + 4096u) & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&done[lvl], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 20000;
     const int G = argc > 2 ? atoi(argv[2]) : 1024;                  // workgroups per launch (MHC-24 levels: 800-2200)
@@ -207,9 +240,37 @@ int main(int argc, char **argv) {
         for (auto &evq : evs) CK(hipEventDestroy(evq));
         CK(hipStreamDestroy(s2));
     }
-    if (argc > 3) return 0;                                         // any third argument: skip the persistent variants
-    // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
+    if (argc > 4) return 0;                                         // a fourth argument: stop here
     Ctl *ctl; CK(hipMalloc(&ctl, sizeof(Ctl)));
+    {   // chained levels in one dispatch (k_chain), M levels per dispatch
+        uint32_t *done; CK(hipMalloc(&done, 4 * (size_t)(N + 64)));
+        for (int M : {2, 4, 16, 64}) {
+            for (int rounds : {2, 5}) {
+                float best = 1e30f; uint32_t aborted = 0;
+                const int NL = (N / M) * M;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CK(hipMemsetAsync(ctl, 0, sizeof(Ctl), s));
+                    CK(hipMemsetAsync(done, 0, 4 * (size_t)(N + 64), s));
+                    CK(hipEventRecord(e0, s));
+                    for (int l0 = 0; l0 < NL; l0 += M) {
+                        if (rounds == 2) hipLaunchKernelGGL((k_chain<2>), dim3(G * M), dim3(256), 0, s, G, l0, rec, st[0], st[1], mask, done, ctl, G * 256);
+                        else hipLaunchKernelGGL((k_chain<5>), dim3(G * M), dim3(256), 0, s, G, l0, rec, st[0], st[1], mask, done, ctl, G * 256);
+                    }
+                    CK(hipEventRecord(e1, s));
+                    CK(hipStreamSynchronize(s));
+                    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+                    Ctl h; CK(hipMemcpy(&h, ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+                    aborted |= h.abort;
+                    if (ms < best) best = ms;
+                }
+                printf("chain%d x%-3d %7.3f us/level   (%d levels, %d workgroups per level, %d levels per dispatch)%s\n", rounds, M, 1e3 * best / NL, NL, G, M,
+                       aborted ? "  ABORTED (spin timeout)" : "");
+            }
+        }
+        CK(hipFree(done));
+    }
+    if (argc > 3) return 0;                                         // a third argument: skip the persistent variants
+    // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
     int dev_cus = 0; CK(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, 0));
     for (int PG : {dev_cus / 8, dev_cus, 2 * dev_cus}) {
         for (int rounds : {2, 5}) {
