@@ -136,6 +136,16 @@ class ShardedSketch:
         caller.wait_stream(self.stream)
         return out
 
+    def _dictionary_ranges(self, dict_t):
+        """[lo, hi) = the slice of the sorted dictionary inside this rank's hash range, and the owner of every dictionary
+        hash; a function of (dictionary, world) only: computed once and kept"""
+        key = (dict_t.data_ptr(), dict_t.numel(), self.world)
+        if getattr(self, "_dict_key", None) != key:
+            split = self.ops.partition(dict_t, self.world).cpu().tolist()
+            self._dict_cache = (int(split[self.rank]), int(split[self.rank + 1]), hash_owner(dict_t, self.world))
+            self._dict_key = key
+        return self._dict_cache
+
     def _lap(self, name):
         if self.laps is not None:
             import time
@@ -183,7 +193,8 @@ class ShardedSketch:
         tail = torch.zeros(W + HIST_BINS + M, dtype=torch.int64, device=self.device)
         tail[me] = rh.numel()
         ops.histogram(rc, tail[W: W + HIST_BINS])
-        ops.rank_dictionary(dict_t, rh, tail[W + HIST_BINS:])
+        lo, hi, owner_t = self._dictionary_ranges(dict_t)  # only the dictionary hashes inside this rank's range can be in rh
+        ops.rank_dictionary(dict_t[lo:hi], rh, tail[W + HIST_BINS + lo: W + HIST_BINS + hi])
         self._lap("histogram + rank_dictionary")
         if multi:
             tail_c = self._c(tail)
@@ -195,7 +206,7 @@ class ShardedSketch:
         sizes = tail[:W]
         base = torch.cumsum(sizes, 0) - sizes            # exclusive scan: first global id of every range
         rank1 = tail[W + HIST_BINS:]
-        ids = torch.where(rank1 > 0, rank1 - 1 + base[hash_owner(dict_t, W)], torch.full_like(rank1, -1))
+        ids = torch.where(rank1 > 0, rank1 - 1 + base[owner_t], torch.full_like(rank1, -1))
         sizes_h = sizes.cpu().tolist()
         self._lap("ids + host read")
         return Score(counts=counts, ids=ids, n_distinct=int(sum(sizes_h)), hist=tail[W: W + HIST_BINS], range_hash=rh, range_count=rc,
