@@ -78,6 +78,7 @@ struct SweepArgs {                                      // generic sweep kernel
     uint16_t *bp;
     unsigned long long *digest;
     int RP;
+    int *progress;                                      // PfCtl::level: the level whose launch is running (dg_dp_sweep.hip: L2 prefetcher)
 };
 
 struct FastArgs {                                       // fast sweep kernel
@@ -91,6 +92,7 @@ struct FastArgs {                                       // fast sweep kernel
     unsigned long long *digest;
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
     uint32_t buf_bytes;                                 // size of one padded state buffer
+    int *progress;                                      // PfCtl::level: the level whose launch is running (L2 prefetcher)
 #ifdef DG_SWEEP_PROBE
     unsigned long long *probe;                          // measurement build: 8 words per level
 #endif
@@ -111,8 +113,12 @@ struct DpState {
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
+    int64_t l2_prefetch = 6;                            // l2_prefetch: levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
     int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
     bool lean_chain = false;
+    hipStream_t pf_stream = nullptr;                    // side stream of the L2 table prefetcher (dg_dp_sweep.hip)
+    hipEvent_t pf_ev = nullptr;
+    int pf_seq = 0;
     mutable int chain_seq = 0;                          // per-launch number of the lean chain walk (ChainSync, dg_dp_trace.hip)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])
     int64_t delta_cap_entries = (int64_t)4 << 30;       // delta_cap_entries: budget of resident score-delta entries
@@ -141,7 +147,7 @@ struct DpState {
     int64_t delta_buf_entries = 0;
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain;
+    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
 #ifdef DG_SWEEP_PROBE
     DevBuf d_probe;
 #endif
@@ -204,6 +210,9 @@ void sweep_prepare(const DpState &S, SweepLaunch &X);
 void sweep_init_state(const DpState &S, hipStream_t s);                  // level 0: every r starts at 0 (:534-535)
 void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s);
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s);
+int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s);
+void sweep_prefetch_end(DpState &S, int le, hipStream_t s);
+void sweep_prefetch_free(DpState &S);
 
 // ---- traceback (dg_dp_trace.hip) ----
 void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s);

@@ -21,6 +21,7 @@ void graphs_clear(DpState &S) {                 // captured level batches: stale
 void dp_state_free(DpState *s) {
     if (!s) return;
     graphs_clear(*s);
+    sweep_prefetch_free(*s);
     { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
     if (s->pool.th.joinable()) s->pool.th.join();
     for (void *q : s->pool.chunks) (void)hipFree(q);
@@ -131,6 +132,7 @@ struct Run {
     // context back to plain launches for good; the batch at hand is then issued again, plainly.
     int sweep_range(int lb, int le, uint16_t *bp_biased) {
         X.A.bp = bp_biased; X.F.bp = bp_biased;
+        if (int rc = sweep_prefetch_begin(S, X, lb, le, n_win() == 1, s)) return rc;
         const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : 1000;
         for (int l0 = lb; l0 < le;) {
             const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
@@ -170,6 +172,7 @@ struct Run {
             }
             l0 = l1;
         }
+        sweep_prefetch_end(S, le, s);
         return DG_OK;
     }
 
@@ -284,6 +287,11 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     }
 #endif
     if (getenv("DG_DEBUG") && S.lean_chain) trace_debug_report(S);
+    if (getenv("DG_DEBUG") && S.pf_stream) {
+        int w[4] = {0, 0, 0, 0};
+        if (hipStreamSynchronize(S.pf_stream) == hipSuccess && hipMemcpy(w, S.d_pfctl.p, sizeof w, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[dipgenie_hip] run: L2 table prefetcher covered %d levels (since load)\n", w[2]);
+    }
     if (getenv("DG_DEBUG"))
         fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)run.n_launch, 1e3 * run.host_enqueue_s,
                 1e6 * run.host_enqueue_s / (double)std::max<int64_t>(run.n_launch, 1));
@@ -377,7 +385,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"digest", &S.want_digest, 0}, {"fast", &S.use_fast, 0}, {"adaptive_rc", &S.adaptive_rc, 0}, {"coop", &S.use_coop, 0},
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
-        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1},
+        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0},
         {"host_threads", &S.host_threads, 1},
     };
     for (auto &o : plain)

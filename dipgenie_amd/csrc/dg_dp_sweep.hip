@@ -433,6 +433,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t state_rsrc(const int32_t *padd
 
 // per-level launch of the fast form: grid = (ceil(nblocks/4), nchunk, k2 [+ 4 per heavy row]), one task per wave (a 3-D
 // grid: splitting a combined index would cost a runtime integer division -- ~40 instructions of a 380-instruction task)
+// workgroup 0 of a launch tells the L2 prefetcher which level is running
+__device__ __forceinline__ void publish_level(int *progress, int lvl) {
+    if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) __hip_atomic_store(progress, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifndef DG_PLAIN_WG
 #define DG_PLAIN_WG 256
 #endif
@@ -443,6 +448,7 @@ __global__ __launch_bounds__(DG_PLAIN_WG) void dp_sweep_fast_kernel(const uint4 
                                                             int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
                                                             FastArgs A, LevelDesc d, int lvl) {
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
+    publish_level(A.progress, lvl);
     const int wv = (int)(threadIdx.x >> 6);
     const int g = (int)blockIdx.x * DG_PLAIN_GW + (wv % DG_PLAIN_GW);    // always launched with DG_PLAIN_WG threads (reading blockDim would be a kernel-argument load)
     const int r0 = ((int)blockIdx.y * DG_PLAIN_CH + wv / DG_PLAIN_GW) * RC;
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
                                                             unsigned long long heavy_hi,                                                  // 16 dwords: preloaded
                                                             FastArgs A, LevelDesc d, int lvl, const uint16_t *dm, int dT, const int32_t *__restrict__ heavy_rows) {
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, A.pad_bytes, dT, A.buf_bytes};
+    publish_level(A.progress, lvl);
     int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
     const int zc = 4 * n_heavy;
@@ -495,6 +502,63 @@ __global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
     }
 }
 
+// L2 table prefetcher.  The look-ahead above gets a level's tables as far as the memory-side Infinity Cache; the two load
+// rounds of a task then cost an Infinity-Cache round trip each.  The L2 is per XCD, so this kernel -- PF_WORKGROUPS one-wave
+// workgroups on a side stream, two per XCD by round-robin dispatch -- reads one word of every 128-byte line of the next
+// levels' tables (row records, slot records, in-edges, row matrices, score deltas) on EVERY XCD, l2_prefetch levels ahead of
+// the level the sweep publishes (workgroup 0 of every sweep launch stores its level).
+// Measured on MHC-24 (sweep, ms): off 589; publishing alone 595; 8 / 16 / 64 workgroups 584.5 / 581.9 / 622-627 (64 pollers
+// on the published word cost more than the prefetch gives: poll-only 638); 3 / 6 / 12 levels ahead 585.6 / 584.5 / 588.9.
+// (A per-level prefetch LAUNCH in the chain made the traced sweep kernels 9 % shorter, 5.26 -> 4.79 us -- most of that was
+// the extra launch absorbing the kernel boundary, not the cache.)
+// Hints only: nothing waits for it; it leaves when the host marks the range done, when a newer range's sequence number
+// appears, or after ~10^5 polls without progress.
+constexpr int PF_WORKGROUPS = 16;
+struct PfCtl { int seq, stop, levels_done, pad_[29]; int level; int pad2_[31]; };      // level: a line of its own
+
+__global__ void dp_pf_ctl_kernel(PfCtl *c, int seq, int level, int stop) {
+    __hip_atomic_store(&c->level, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->stop, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&c->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__restrict__ descs, FastArgs F, PfCtl *ctl, int seq, int lb, int le, int ahead, int delta_resident) {
+    __shared__ int dump[64];
+    // a load whose data nobody wants: straight into an LDS dump word per lane (no destination register, nothing to wait for)
+#define DG_DROP_LOAD(PTR) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(PTR), (__attribute__((address_space(3))) void *)dump, 4, 0, 0)
+    const int lane = (int)threadIdx.x, slot = (int)(blockIdx.x >> 3), nslot = (int)(gridDim.x >> 3);
+    int idle = 0, last = INT32_MIN, done = 0;
+    int *level_word = &ctl->level;
+    auto lines = [&](const char *base, long long bytes) {               // this workgroup's share of the 128-byte lines of [base, base + bytes)
+        if (bytes <= 0) return;
+        const uintptr_t a = (uintptr_t)base & ~(uintptr_t)127;
+        const int n = (int)(((uintptr_t)base + (uintptr_t)bytes - a + 127) >> 7);
+        for (int t = slot * 64 + lane; t < n; t += nslot * 64) DG_DROP_LOAD((const char *)a + ((size_t)t << 7));
+    };
+    int polls = 0;
+    for (int lp = lb; lp < le;) {
+        // one word is polled (the line the sweep's workgroup 0 stores to: every poll competes with that store); the range's
+        // sequence number and stop flag, in another line, every 32nd time
+        if ((polls++ & 31) == 0 &&
+            (__hip_atomic_load(&ctl->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq || __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+        const int lv = __builtin_amdgcn_readfirstlane(__hip_atomic_load(level_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (lv == last) { if (++idle > 100000) break; } else { idle = 0; last = lv; }
+        if (lp <= lv) lp = lv + 1;                                      // overtaken: level lv is running
+        if (lp >= le) break;
+        if (lp - lv > ahead) { __builtin_amdgcn_s_sleep(48); continue; }
+        const LevelDesc &d = descs[lp];
+        const int k2 = __builtin_amdgcn_readfirstlane(d.k2), T = __builtin_amdgcn_readfirstlane(d.T);
+        lines((const char *)(F.rowrec + d.b0), 16LL * k2);
+        lines((const char *)(F.slots + d.slot_first), 512LL * d.nblocks);
+        lines((const char *)(F.in_edge + d.in_base), 4LL * T);
+        if (d.rowx_stride > 0) lines((const char *)(F.rowx + d.rowx_off), 4LL * k2 * d.rowx_stride);
+        if (delta_resident && d.delta_off >= 0 && (long long)T * T <= (128 << 10)) lines((const char *)(F.delta + d.delta_off), 2LL * T * T);
+        ++lp; ++done;
+    }
+    if (lane == 0 && blockIdx.x == 0) atomicAdd(&ctl->levels_done, done);
+#undef DG_DROP_LOAD
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -514,6 +578,7 @@ void sweep_prepare(const DpState &S, SweepLaunch &X) {
 #ifdef DG_SWEEP_PROBE
     F.probe = S.d_probe.as<unsigned long long>();
 #endif
+    F.progress = A.progress = &S.d_pfctl.as<PfCtl>()->level;
     F.pad_bytes = (int)(4 * S.pad_front);
     F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
 }
@@ -633,6 +698,30 @@ void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, h
     if (tot <= 0) return;
     const unsigned grid = (unsigned)std::min<long long>((tot + 255) / 256, 2048);
     hipLaunchKernelGGL(dp_warm_tables_kernel, dim3(grid), dim3(256), 0, s, W);
+}
+
+// L2 prefetcher of the sweep range [lb, le): control words set in stream order on s, the prefetcher itself on the side stream
+int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s) {
+    if (S.l2_prefetch <= 0 || !X.small_state || !S.use_fast || le - lb < 64) return DG_OK;
+    if (!S.pf_stream) {
+        if (hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.pf_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError(); S.pf_stream = nullptr; S.l2_prefetch = 0; return DG_OK;       // no side stream: no prefetcher
+        }
+    }
+    const int seq = ++S.pf_seq;
+    hipLaunchKernelGGL(dp_pf_ctl_kernel, dim3(1), dim3(1), 0, s, S.d_pfctl.as<PfCtl>(), seq, lb - 1, 0);
+    DG_HIP(hipEventRecord(S.pf_ev, s));
+    DG_HIP(hipStreamWaitEvent(S.pf_stream, S.pf_ev, 0));
+    hipLaunchKernelGGL(dp_l2_prefetch_kernel, dim3(PF_WORKGROUPS), dim3(64), 0, S.pf_stream, S.d_descs.as<LevelDesc>(), X.F, S.d_pfctl.as<PfCtl>(), seq, lb, le,
+                       (int)S.l2_prefetch, delta_resident ? 1 : 0);
+    return DG_OK;
+}
+void sweep_prefetch_end(DpState &S, int le, hipStream_t s) {
+    if (S.pf_stream && S.l2_prefetch > 0) hipLaunchKernelGGL(dp_pf_ctl_kernel, dim3(1), dim3(1), 0, s, S.d_pfctl.as<PfCtl>(), S.pf_seq, le, 1);
+}
+void sweep_prefetch_free(DpState &S) {
+    if (S.pf_stream) { (void)hipStreamSynchronize(S.pf_stream); (void)hipStreamDestroy(S.pf_stream); S.pf_stream = nullptr; }
+    if (S.pf_ev) { (void)hipEventDestroy(S.pf_ev); S.pf_ev = nullptr; }
 }
 
 }  // namespace dgi

@@ -553,6 +553,8 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
     if (int rc = S.d_chain.ensure(128)) return rc;                 // ChainState, and ChainSync at +64
+    if (int rc = S.d_pfctl.ensure(256)) return rc;                  // PfCtl of the L2 table prefetcher
+    DG_HIP(hipMemsetAsync(S.d_pfctl.p, 0, 256, s));
     DG_HIP(hipMemsetAsync(S.d_chain.p, 0, 128, s)); S.chain_seq = 0;
     S.pad_front = 2 * (int64_t)B.max_k;
     const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)B.max_k);

@@ -8,6 +8,9 @@ ctx = capi.Context(0)
 g = capi.DpGraphArrays.load(sys.argv[1])
 ctx.dp_set_option("fast", int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 if os.environ.get("DG_SYNC_EVERY"): ctx.dp_set_option("sync_every", int(os.environ["DG_SYNC_EVERY"]))
+if os.environ.get("DG_OPTS"):
+    for kv in os.environ["DG_OPTS"].split(","):
+        k_, v_ = kv.split("="); ctx.dp_set_option(k_, int(v_))
 if os.environ.get("DG_GRAPH_BATCH"): ctx.dp_set_option("graph_batch", int(os.environ["DG_GRAPH_BATCH"]))
 ctx.dp_load_graph(g)
 for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
