@@ -35,7 +35,7 @@ for v, c, _ in sweep:
     assert c % passes == 0, (v, c)
     prof[v] = prof.get(v, 0) + c // passes
 other = {r["Name"].split("(")[0].replace("void dgi::", "").replace("dgi::", ""): (int(r["Calls"]) // passes, float(r["TotalDurationNs"]) / passes / 1e6)
-         for r in stats if any(k in r["Name"] for k in ("dp_trace", "dp_delta", "dp_warm", "dp_edge"))}
+         for r in stats if any(k in r["Name"] for k in ("dp_trace", "dp_delta", "dp_warm", "dp_edge", "dp_l2_prefetch", "dp_pf_ctl"))}
 launches = calls // passes
 roof = bench["roofline"]
 assert launches == roof["launches"], (launches, roof["launches"])
