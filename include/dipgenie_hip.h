@@ -91,6 +91,17 @@ int dg_dp_solve_diploid(dg_ctx *, const dg_dp_graph *, dg_dp_result *);   /* = l
 /* debug/parity: copy the per-level digest (same definition as the oracle's level_digest) of the
  * last run; out has n_levels entries, entry 0 unused. Requires dg_dp_set_option("digest",1). */
 int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
+/* parity / test / tuning knobs of the DP (none is needed in normal use; unknown keys fail with DG_ERR_ARG):
+ *   digest 0|1            accumulate the per-level digests
+ *   fast 0|1              0: generic sweep kernel only          adaptive_rc 0|1   0: one chunk of all r per task
+ *   coop 0|1|2            cooperative fan-in rows off / by cost model / whenever possible
+ *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1    lean chain walk where the lattice allows it (next load)
+ *   graph_batch n         levels per hipGraph batch (-1: default 1000, 0: plain launches)
+ *   l2_prefetch n         levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
+ *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
+ *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
+ *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
+ *   rc_t0_ns, rc_tg_ps, rc_tw_ps, rc_cap, bp_nt_min_cells, max_blocks, host_threads   cost model / launch tuning */
 int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
 /* measurement: which sweep kernel variants the last dg_dp_run launched, as "name:count name:count ..." (the names
  * rocprofv3 reports, abbreviated); lets a profile taken in another process be matched against this run. */
