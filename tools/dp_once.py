@@ -16,4 +16,4 @@ ctx.dp_load_graph(g)
 for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     out = ctx.dp_run()
     tm = ctx.dp_timing()
-    print("pass", it, "value", out.value, "fwd_ms", round(tm.forward_ms, 1), "tb_ms", round(tm.traceback_ms, 1), flush=True)
+    print("pass", it, "value", out.value, "delta_ms", round(tm.delta_ms, 2), "fwd_ms", round(tm.forward_ms, 1), "tb_ms", round(tm.traceback_ms, 1), "total_ms", round(tm.total_ms, 1), flush=True)
