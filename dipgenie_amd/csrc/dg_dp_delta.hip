@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restri
             if ((fu | fv) == 0u) out[ee[u]] = 0;                            // no colour on either edge
             else if (fv == 0u) out[ee[u]] = eself[d.in_base + eu8[u]];      // one coloured edge: its own score
             else if (fu == 0u) out[ee[u]] = eself[d.in_base + ev8[u]];
-            else s_q[atomicAdd(&s_n, 1)] = (uint16_t)((q0 + u) * 256 + (int)threadIdx.x);   // both coloured: merge (pass 2)
+            else if (eu8[u] <= ev8[u]) s_q[atomicAdd(&s_n, 1)] = (uint16_t)((q0 + u) * 256 + (int)threadIdx.x);   // both coloured: merge (pass 2);
+            // the score is symmetric in (e_u, e_v) -- unions of the two sources' lists against unions of the two destinations' -- so the
+            // pair with e_u > e_v is left to the workgroup that holds its mirror image, which writes both entries
         }
     }
     __syncthreads();
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void dp_delta_kernel(const LevelDesc *__restri
         if ((ff & 3u) == 3u) sc += score_inter(col, u1, v1, u2, v2);
         if ((ff & 12u) != 0u) sc += score_symd(col, u1, v1, u2, v2);
         out[e] = (uint16_t)sc;
+        if (eu != ev) out[(int64_t)ev * d.T + eu] = (uint16_t)sc;
     }
 }
 
