@@ -109,7 +109,7 @@ struct DpState {
     int64_t max_blocks = 1024;                          // max_blocks: grid of the generic kernel
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's table construction
-    int64_t bp_nt_min_cells = 16384;                    // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
+    int64_t bp_nt_min_cells = 262144;                   // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)

@@ -618,8 +618,9 @@ static void choose_rc(const DpState &S, const LevelDesc &d, int l, int rc_sel, i
 
 void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
     LevelDesc &d = S.descs[l];
-    // tiny levels end sooner with write-back stores (3.6 vs 4.2 us per level on MHC_4), big ones with
-    // non-temporal ones that keep the once-written lattice out of the L2
+    // small and mid-sized levels end sooner with write-back back-pointer stores (3.6 vs 4.2 us per level on MHC_4; threshold
+    // 16 K / 64 K / 256 K / 1 M / 4 M cells: MHC-24 sweep 580 / 575 / 574 / 579 / 586 ms), big ones with non-temporal ones that
+    // keep the once-written lattice out of the L2
     d.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
     if (d.fast_ok && X.small_state && S.RP <= 65535 && S.use_fast) {
         int rc;
