@@ -116,6 +116,12 @@ struct DpState {
     int64_t l2_prefetch = 6;                            // l2_prefetch: levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
     int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
     bool lean_chain = false;
+    // single-window score deltas computed beside the sweep: piece k (transitions of levels >= delta_piece_level[k]) signals delta_piece_ev[k]
+    hipStream_t delta_stream = nullptr;
+    std::vector<hipEvent_t> delta_piece_ev;
+    std::vector<int32_t> delta_piece_level;
+    int delta_piece_next = 0;                           // first piece the sweep has not waited for yet
+    int64_t delta_overlap = 1;                          // delta_overlap: 0 = the whole window before the sweep (option)
     hipStream_t pf_stream = nullptr;                    // side stream of the L2 table prefetcher (dg_dp_sweep.hip)
     hipEvent_t pf_ev = nullptr;
     int pf_seq = 0;
@@ -198,6 +204,8 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g);
 void delta_launch_edge_flags(const DpState &S, hipStream_t s);
 // (re)computes the matrices of window w into d_delta; returns the pointer biased so that ptr[LevelDesc::delta_off] is valid
 const uint16_t *delta_launch_window(DpState &S, int w, hipStream_t s);
+const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s);          // one window: first piece on s, the rest on a side stream (events in delta_piece_*)
+void delta_overlap_free(DpState &S);
 
 // ---- level sweep (dg_dp_sweep.hip) ----
 struct SweepLaunch {                     // per-run launch context

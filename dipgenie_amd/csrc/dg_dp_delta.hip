@@ -131,4 +131,57 @@ const uint16_t *delta_launch_window(DpState &S, int w, hipStream_t s) {
     return biased;
 }
 
+// The single-window case beside the sweep.  The deltas depend on nothing the sweep produces, and the sweep of level l needs the
+// matrix of level l only: the first piece (the transitions of the first DELTA_HEAD levels) runs on the sweep's stream, the
+// remaining pieces on a side stream, each followed by an event that the sweep waits for before it issues the piece's first
+// level (dg_dp_run.hip: sweep_range).  The delta kernel fills ~35 levels' worth of matrices in the time the sweep takes for
+// one level, so those waits are satisfied long before they are reached; they are what makes the overlap correct.
+// MHC-24: 13.0 ms of delta before the sweep become 1.1-1.3 ms, the sweep beside the pieces runs 5 ms longer: pass 634 -> 626 ms
+// (a lowest-priority side stream: 628-630 ms, no better).
+constexpr int DELTA_PIECES = 8, DELTA_HEAD = 2000;
+
+const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s) {
+    const int nt = (int)S.dtrans_host.size();
+    const bool forced = S.delta_overlap == 2;                          // (tests: small graphs too)
+    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && S.L < 16 * DELTA_HEAD)) return delta_launch_window(S, 0, s);
+    const int head = forced ? std::max(2, S.L / 16) : DELTA_HEAD;
+    if (!S.delta_stream) {
+        if (hipStreamCreateWithFlags(&S.delta_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.delta_stream = nullptr; S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
+        S.delta_piece_ev.assign(DELTA_PIECES, nullptr);
+        for (auto &e : S.delta_piece_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
+    }
+    // piece boundaries in transitions: the head, then equal shares of the rest
+    std::vector<int> cut(DELTA_PIECES + 1, nt);
+    cut[0] = 0;
+    cut[1] = (int)(std::lower_bound(S.dtrans_host.begin(), S.dtrans_host.end(), head) - S.dtrans_host.begin());
+    cut[1] = std::max(1, std::min(cut[1], nt - (DELTA_PIECES - 1)));
+    for (int k = 2; k < DELTA_PIECES; ++k) cut[k] = cut[1] + (int)((int64_t)(nt - cut[1]) * (k - 1) / (DELTA_PIECES - 1));
+    const int64_t base_off = S.descs[S.dtrans_host[0]].delta_off;
+    uint16_t *out = S.d_delta.as<uint16_t>() + DELTA_PAD - base_off;
+    S.delta_piece_level.assign(DELTA_PIECES, 0);
+    hipEvent_t &gate = S.delta_piece_ev[0];                           // the side stream starts after what precedes on s (previous pass's readers)
+    (void)hipEventRecord(gate, s);
+    (void)hipStreamWaitEvent(S.delta_stream, gate, 0);
+    for (int k = 0; k < DELTA_PIECES; ++k) {
+        const int t0 = cut[k], t1 = cut[k + 1];
+        S.delta_piece_level[k] = t0 < nt ? S.dtrans_host[t0] : S.L;
+        if (t1 <= t0) continue;
+        const int64_t b0 = S.dblk_first_host[t0], b1 = S.dblk_first_host[t1];
+        hipStream_t q = k == 0 ? s : S.delta_stream;
+        hipLaunchKernelGGL(dp_delta_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0, q, S.d_descs.as<LevelDesc>(), S.d_dtrans.as<int32_t>(),
+                           S.d_dblk_first.as<int64_t>(), nt, S.d_in_edge.as<uint32_t>(), S.d_in_dst.as<int32_t>(), colour_csr(S),
+                           out, b0, S.d_eflag.as<uint8_t>(), S.d_eself.as<uint16_t>());
+        if (k > 0) (void)hipEventRecord(S.delta_piece_ev[k], S.delta_stream);
+    }
+    S.delta_piece_next = 1;
+    S.cur_win = 0;
+    return out;
+}
+
+void delta_overlap_free(DpState &S) {
+    if (S.delta_stream) { (void)hipStreamSynchronize(S.delta_stream); (void)hipStreamDestroy(S.delta_stream); S.delta_stream = nullptr; }
+    for (auto &e : S.delta_piece_ev) if (e) (void)hipEventDestroy(e);
+    S.delta_piece_ev.clear();
+}
+
 }  // namespace dgi

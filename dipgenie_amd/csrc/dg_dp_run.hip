@@ -10,6 +10,8 @@
 
 namespace dgi {
 
+constexpr int DELTA_NO_PIECES = 1 << 30;
+
 double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 void graphs_clear(DpState &S) {                 // captured level batches: stale as soon as the graph, the lattice or an option changes
@@ -22,6 +24,7 @@ void dp_state_free(DpState *s) {
     if (!s) return;
     graphs_clear(*s);
     sweep_prefetch_free(*s);
+    delta_overlap_free(*s);
     { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
     if (s->pool.th.joinable()) s->pool.th.join();
     for (void *q : s->pool.chunks) (void)hipFree(q);
@@ -137,6 +140,11 @@ struct Run {
         for (int l0 = lb; l0 < le;) {
             const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
             const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, le) : le;
+            // score deltas computed beside the sweep (delta_launch_overlapped): the stream waits for the pieces that hold a level below l1
+            while (S.delta_piece_next < (int)S.delta_piece_level.size() && S.delta_piece_level[S.delta_piece_next] < l1) {
+                DG_HIP(hipStreamWaitEvent(s, S.delta_piece_ev[S.delta_piece_next], 0));
+                ++S.delta_piece_next;
+            }
             hipGraphExec_t *slot = nullptr;
             bool capturing = false;
             if (use_graph) {
@@ -214,7 +222,8 @@ struct Run {
         const int n_seg = (int)S.seg_begin.size() - 1, n_chunks_all = (int)S.chunk_begin.size() - 1;
         DG_HIP(hipEventRecord(S.ev[0], s));
         S.cur_win = -1;
-        if (n_win() == 1 && S.n_delta_blocks > 0) load_window(0);      // everything fits: computed once, up front (delta_ms)
+        S.delta_piece_next = DELTA_NO_PIECES;
+        if (n_win() == 1 && S.n_delta_blocks > 0) X.A.delta = X.F.delta = delta_launch_overlapped(S, s);   // everything fits: the head up front (delta_ms), the rest beside the sweep
         DG_HIP(hipEventRecord(S.ev[1], s));
         if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
 #ifdef DG_SWEEP_PROBE
@@ -385,7 +394,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"digest", &S.want_digest, 0}, {"fast", &S.use_fast, 0}, {"adaptive_rc", &S.adaptive_rc, 0}, {"coop", &S.use_coop, 0},
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
-        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0},
+        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0},
         {"host_threads", &S.host_threads, 1},
     };
     for (auto &o : plain)
