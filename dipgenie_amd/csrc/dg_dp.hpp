@@ -128,7 +128,7 @@ struct DpState {
     mutable int chain_seq = 0;                          // per-launch number of the lean chain walk (ChainSync, dg_dp_trace.hip)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])
     int64_t delta_cap_entries = (int64_t)4 << 30;       // delta_cap_entries: budget of resident score-delta entries
-    int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 24000, rc_tw_ps = 50;   // rc_*: cost model of the per-level RC choice
+    int64_t rc_cap = 65536, rc_t0_ns = 3000, rc_tg_ps = 20000, rc_tw_ps = 50;   // rc_*: cost model of the per-level RC choice
     size_t chunk_units_cfg = (size_t)4 << 30;           // lattice_chunk_cells: size of one lattice chunk (16-bit units)
     // ---- lattice segments: destination levels [seg_begin[s], seg_begin[s+1]); one segment = whole lattice resident.
     // More than one = checkpoint + recompute (value-only pass, then each segment re-swept with back-pointers, last first).

@@ -136,26 +136,30 @@ const uint16_t *delta_launch_window(DpState &S, int w, hipStream_t s) {
 // remaining pieces on a side stream, each followed by an event that the sweep waits for before it issues the piece's first
 // level (dg_dp_run.hip: sweep_range).  The delta kernel fills ~35 levels' worth of matrices in the time the sweep takes for
 // one level, so those waits are satisfied long before they are reached; they are what makes the overlap correct.
-// MHC-24: 13.0 ms of delta before the sweep become 1.1-1.3 ms, the sweep beside the pieces runs 5 ms longer: pass 634 -> 626 ms
+// MHC-24: 13.0 ms of delta before the sweep become 1.1-1.3 ms with a head of 2,000 levels (0.1 ms with 250 and fourfold growing pieces), the sweep beside the pieces runs 5 ms longer: pass 634 -> 626 ms
 // (a lowest-priority side stream: 628-630 ms, no better).
-constexpr int DELTA_PIECES = 8, DELTA_HEAD = 2000;
+constexpr int DELTA_PIECES = 8, DELTA_HEAD = 250;
 
 const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s) {
     const int nt = (int)S.dtrans_host.size();
     const bool forced = S.delta_overlap == 2;                          // (tests: small graphs too)
-    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && S.L < 16 * DELTA_HEAD)) return delta_launch_window(S, 0, s);
-    const int head = forced ? std::max(2, S.L / 16) : DELTA_HEAD;
+    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && S.L < 32000)) return delta_launch_window(S, 0, s);
+    const int head = forced ? std::max(2, S.L / 256) : DELTA_HEAD;
     if (!S.delta_stream) {
         if (hipStreamCreateWithFlags(&S.delta_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.delta_stream = nullptr; S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
         S.delta_piece_ev.assign(DELTA_PIECES, nullptr);
         for (auto &e : S.delta_piece_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
     }
-    // piece boundaries in transitions: the head, then equal shares of the rest
+    // piece boundaries in transitions: pieces that grow fourfold from the head on (a piece must be finished before the sweep reaches
+    // its first level: the sweep needs ~4 us per level, the delta kernel ~0.1-0.15 us), then equal shares of the rest
     std::vector<int> cut(DELTA_PIECES + 1, nt);
     cut[0] = 0;
-    cut[1] = (int)(std::lower_bound(S.dtrans_host.begin(), S.dtrans_host.end(), head) - S.dtrans_host.begin());
-    cut[1] = std::max(1, std::min(cut[1], nt - (DELTA_PIECES - 1)));
-    for (int k = 2; k < DELTA_PIECES; ++k) cut[k] = cut[1] + (int)((int64_t)(nt - cut[1]) * (k - 1) / (DELTA_PIECES - 1));
+    int lvl_cut = head;
+    for (int k = 1; k <= 4; ++k, lvl_cut *= 4) {
+        cut[k] = (int)(std::lower_bound(S.dtrans_host.begin(), S.dtrans_host.end(), lvl_cut) - S.dtrans_host.begin());
+        cut[k] = std::max(cut[k - 1] + 1, std::min(cut[k], nt - (DELTA_PIECES - k)));
+    }
+    for (int k = 5; k < DELTA_PIECES; ++k) cut[k] = cut[4] + (int)((int64_t)(nt - cut[4]) * (k - 4) / (DELTA_PIECES - 4));
     const int64_t base_off = S.descs[S.dtrans_host[0]].delta_off;
     uint16_t *out = S.d_delta.as<uint16_t>() + DELTA_PAD - base_off;
     S.delta_piece_level.assign(DELTA_PIECES, 0);
