@@ -222,7 +222,7 @@ __device__ __forceinline__ void lean_step(LeanWalk &W, int RP, const LeanDesc &N
 // level.  Helper workgroups ON THE WALKER'S XCD (the L2 is per XCD; a helper wave on the walker's own CU was measured
 // and is worse than none: 80 vs 54 ms, its misses queue in front of the walker's loads in the CU's in-order memory
 // pipeline) read those planes, one load per 128-byte line with the data dropped, and the level's row records, keeping
-// up to LEAN_AHEAD_MAX levels ahead of the position the walker publishes every eight levels; the walker's loads then
+// up to LEAN_AHEAD_MAX levels ahead of the position the walker publishes every 16 levels; the walker's loads then
 // hit the L2.  A wrong guess (a third recombination inside the window) costs an ordinary miss, nothing else.
 // Protocol (ChainSync, in global memory; relaxed agent-scope atomics -- hints, nothing depends on their order): the
 // walker (block 0) publishes its XCC id and seq << 32 | level; every other block of the launch whose XCC id matches
@@ -230,6 +230,7 @@ __device__ __forceinline__ void lean_step(LeanWalk &W, int RP, const LeanDesc &N
 // helper from acting on the previous launch's words; whatever it reads, it only ever touches levels of [l_lo, l_hi].
 constexpr int LEAN_AHEAD_MAX = 96, LEAN_AHEAD_BYTES = 3 << 19;      // window: at most 96 levels and ~1.5 MB of planes
 constexpr int LEAN_PREFETCHERS = 8, LEAN_BLOCKS = 80, LEAN_POLL_EVERY = 4;
+constexpr int LEAN_PUBLISH_MASK = 8;             // the walker publishes its position every 16 levels (every 8: 47.0 ms, 16: 44.5, 32: 44.9 on MHC-24)
 struct ChainSync { unsigned long long pos; int r, xcc; int ticket[2]; int n_helpers, n_levels; };   // (the last two: DG_DEBUG statistics)
 
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20); }   // HW_REG_XCC_ID[3:0]
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc
 #define DG_LEAN_STEP(T, X, Y) { const LeanDesc DN = DG_DESC((T) + 1); lean_step(W, RP, DN, rowrec, in_edge, park_u, park_v, (T), lane, X, Y); }
 #define DG_LEAN_STOP(T) (W.bad || (T) >= n)
             for (int t = 0; t < n; t += 8) {
-                if (lane == 0) DG_PUBLISH(base - t, W.r);
+                if (lane == 0 && (t & LEAN_PUBLISH_MASK) == 0) DG_PUBLISH(base - t, W.r);
                 DG_LEAN_STEP(t, A, B);     if (DG_LEAN_STOP(t + 1)) break;
                 DG_LEAN_STEP(t + 1, B, A); if (DG_LEAN_STOP(t + 2)) break;
                 DG_LEAN_STEP(t + 2, A, B); if (DG_LEAN_STOP(t + 3)) break;
