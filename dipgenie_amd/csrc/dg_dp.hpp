@@ -18,6 +18,7 @@
 //     cost model and gives rows with many in-edges cooperative workgroups.
 #pragma once
 #include <condition_variable>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -98,7 +99,13 @@ struct FastArgs {                                       // fast sweep kernel
 #endif
 };
 
+inline std::atomic<int> &dp_states_alive() { static std::atomic<int> n{0}; return n; }      // DP states of this process (L2 prefetcher: one at most)
+
 struct DpState {
+    DpState() { ++dp_states_alive(); }
+    ~DpState() { --dp_states_alive(); }
+    DpState(const DpState &) = delete;
+    DpState &operator=(const DpState &) = delete;
     int32_t nV = 0, L = 0, R = 0, RP = 0, cap = 0;
     bool loaded = false;
     // ---- options (dg_dp_set_option) ----
@@ -117,14 +124,14 @@ struct DpState {
     int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
     bool lean_chain = false;
     // single-window score deltas computed beside the sweep: piece k (transitions of levels >= delta_piece_level[k]) signals delta_piece_ev[k]
-    hipStream_t delta_stream = nullptr;
     std::vector<hipEvent_t> delta_piece_ev;
     std::vector<int32_t> delta_piece_level;
     int delta_piece_next = 0;                           // first piece the sweep has not waited for yet
     int64_t delta_overlap = 1;                          // delta_overlap: 0 = the whole window before the sweep (option)
-    hipStream_t pf_stream = nullptr;                    // side stream of the L2 table prefetcher (dg_dp_sweep.hip)
+    hipStream_t pf_stream = nullptr;                    // the ONE side stream: score-delta pieces, then the L2 table prefetcher (dg_dp_sweep.hip)
     hipEvent_t pf_ev = nullptr;
     int pf_seq = 0;
+    int pf_tested = 0;                                  // 0: the side stream's concurrency with the sweep's stream not yet probed, 1: probed
     mutable int chain_seq = 0;                          // per-launch number of the lean chain walk (ChainSync, dg_dp_trace.hip)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])
     int64_t delta_cap_entries = (int64_t)4 << 30;       // delta_cap_entries: budget of resident score-delta entries

@@ -143,13 +143,20 @@ constexpr int DELTA_PIECES = 8, DELTA_HEAD = 250;
 const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s) {
     const int nt = (int)S.dtrans_host.size();
     const bool forced = S.delta_overlap == 2;                          // (tests: small graphs too)
-    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && S.L < 32000)) return delta_launch_window(S, 0, s);
+    // (one DP state per process only: with several, a side stream may share a hardware queue with another state's sweep and its pieces
+    // would queue behind whole batches of that sweep)
+    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && (S.L < 32000 || dp_states_alive().load() > 1))) return delta_launch_window(S, 0, s);
     const int head = forced ? std::max(2, S.L / 256) : DELTA_HEAD;
-    if (!S.delta_stream) {
-        if (hipStreamCreateWithFlags(&S.delta_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.delta_stream = nullptr; S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
+    // ONE side stream for these pieces and for the L2 table prefetcher (dg_dp_sweep.hip).  With a stream each, the prefetcher -- a kernel
+    // that lives as long as its range's sweep -- and the pieces could meet in one hardware queue (HIP maps streams onto a few of them):
+    // the sweep then waited for a piece that waited behind a prefetcher that waited for the sweep.  Seen with GPU_MAX_HW_QUEUES=8: 4.1 s
+    // per sweep.  In one stream the pieces always precede the prefetcher.
+    if (!S.pf_stream && hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.pf_stream = nullptr; S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
+    if (S.delta_piece_ev.empty()) {
         S.delta_piece_ev.assign(DELTA_PIECES, nullptr);
         for (auto &e : S.delta_piece_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.delta_overlap = 0; return delta_launch_window(S, 0, s); }
     }
+    hipStream_t side = S.pf_stream;
     // piece boundaries in transitions: pieces that grow fourfold from the head on (a piece must be finished before the sweep reaches
     // its first level: the sweep needs ~4 us per level, the delta kernel ~0.1-0.15 us), then equal shares of the rest
     std::vector<int> cut(DELTA_PIECES + 1, nt);
@@ -165,25 +172,24 @@ const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s) {
     S.delta_piece_level.assign(DELTA_PIECES, 0);
     hipEvent_t &gate = S.delta_piece_ev[0];                           // the side stream starts after what precedes on s (previous pass's readers)
     (void)hipEventRecord(gate, s);
-    (void)hipStreamWaitEvent(S.delta_stream, gate, 0);
+    (void)hipStreamWaitEvent(side, gate, 0);
     for (int k = 0; k < DELTA_PIECES; ++k) {
         const int t0 = cut[k], t1 = cut[k + 1];
         S.delta_piece_level[k] = t0 < nt ? S.dtrans_host[t0] : S.L;
         if (t1 <= t0) continue;
         const int64_t b0 = S.dblk_first_host[t0], b1 = S.dblk_first_host[t1];
-        hipStream_t q = k == 0 ? s : S.delta_stream;
+        hipStream_t q = k == 0 ? s : side;
         hipLaunchKernelGGL(dp_delta_kernel, dim3((unsigned)(b1 - b0)), dim3(256), 0, q, S.d_descs.as<LevelDesc>(), S.d_dtrans.as<int32_t>(),
                            S.d_dblk_first.as<int64_t>(), nt, S.d_in_edge.as<uint32_t>(), S.d_in_dst.as<int32_t>(), colour_csr(S),
                            out, b0, S.d_eflag.as<uint8_t>(), S.d_eself.as<uint16_t>());
-        if (k > 0) (void)hipEventRecord(S.delta_piece_ev[k], S.delta_stream);
+        if (k > 0) (void)hipEventRecord(S.delta_piece_ev[k], side);
     }
     S.delta_piece_next = 1;
     S.cur_win = 0;
     return out;
 }
 
-void delta_overlap_free(DpState &S) {
-    if (S.delta_stream) { (void)hipStreamSynchronize(S.delta_stream); (void)hipStreamDestroy(S.delta_stream); S.delta_stream = nullptr; }
+void delta_overlap_free(DpState &S) {                                  // (the side stream itself: sweep_prefetch_free, called first)
     for (auto &e : S.delta_piece_ev) if (e) (void)hipEventDestroy(e);
     S.delta_piece_ev.clear();
 }

@@ -512,9 +512,10 @@ __global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
 // (A per-level prefetch LAUNCH in the chain made the traced sweep kernels 9 % shorter, 5.26 -> 4.79 us -- most of that was
 // the extra launch absorbing the kernel boundary, not the cache.)
 // Hints only: nothing waits for it; it leaves when the host marks the range done, when a newer range's sequence number
-// appears, or after ~10^5 polls without progress.
+// appears, or after 0.3 ms without progress.
 constexpr int PF_WORKGROUPS = 16;
-struct PfCtl { int seq, stop, levels_done, pad_[29]; int level; int pad2_[31]; };      // level: a line of its own
+constexpr unsigned long long PF_IDLE_TICKS = 30000;      // 0.3 ms
+struct PfCtl { int seq, stop, levels_done, probe, probe_ok, pad_[27]; int level; int pad2_[31]; };      // level: a line of its own
 
 __global__ void dp_pf_ctl_kernel(PfCtl *c, int seq, int level, int stop) {
     __hip_atomic_store(&c->level, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -522,12 +523,28 @@ __global__ void dp_pf_ctl_kernel(PfCtl *c, int seq, int level, int stop) {
     __hip_atomic_store(&c->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Does the side stream run beside the sweep's stream?  HIP maps streams onto a handful of hardware queues; a prefetcher that
+// shares the sweep's queue would sit in front of the levels it is waiting for until it gives up.  Probed once per state: a
+// kernel on the side stream waits up to ~2 ms (100 MHz counter) for a word that a kernel issued AFTER it on the sweep's
+// stream sets -- it sees it only if the two really run concurrently.
+__global__ void dp_pf_probe_wait_kernel(PfCtl *c, int token) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int ok = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 200000ULL) {
+        if (__hip_atomic_load(&c->probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    c->probe_ok = ok;
+}
+__global__ void dp_pf_probe_set_kernel(PfCtl *c, int token) { __hip_atomic_store(&c->probe, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__restrict__ descs, FastArgs F, PfCtl *ctl, int seq, int lb, int le, int ahead, int delta_resident) {
     __shared__ int dump[64];
     // a load whose data nobody wants: straight into an LDS dump word per lane (no destination register, nothing to wait for)
 #define DG_DROP_LOAD(PTR) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(PTR), (__attribute__((address_space(3))) void *)dump, 4, 0, 0)
     const int lane = (int)threadIdx.x, slot = (int)(blockIdx.x >> 3), nslot = (int)(gridDim.x >> 3);
-    int idle = 0, last = INT32_MIN, done = 0;
+    int last = INT32_MIN, done = 0;
+    unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
     int *level_word = &ctl->level;
     auto lines = [&](const char *base, long long bytes) {               // this workgroup's share of the 128-byte lines of [base, base + bytes)
         if (bytes <= 0) return;
@@ -542,7 +559,12 @@ __global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__r
         if ((polls++ & 31) == 0 &&
             (__hip_atomic_load(&ctl->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq || __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
         const int lv = __builtin_amdgcn_readfirstlane(__hip_atomic_load(level_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (lv == last) { if (++idle > 100000) break; } else { idle = 0; last = lv; }
+        // Leaves after PF_IDLE_TICKS (100 MHz) without progress.  HIP maps streams and graph launches onto a few hardware queues;
+        // if this kernel ever lands in front of the sweep in one queue, the sweep cannot start until it is gone (seen with
+        // GPU_MAX_HW_QUEUES=8: every range waited out the former 10^5-poll limit, a 6.5x slower sweep).  0.3 ms per range bounds
+        // that case at well under 1 % of a pass; a longer legitimate gap (the capturing pass) merely ends the prefetching of the range.
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (lv != last) { last = lv; t_last = now; } else if (now - t_last > PF_IDLE_TICKS) break;
         if (lp <= lv) lp = lv + 1;                                      // overtaken: level lv is running
         if (lp >= le) break;
         if (lp - lv > ahead) { __builtin_amdgcn_s_sleep(48); continue; }
@@ -704,9 +726,23 @@ void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, h
 // L2 prefetcher of the sweep range [lb, le): control words set in stream order on s, the prefetcher itself on the side stream
 int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s) {
     if (S.l2_prefetch <= 0 || !X.small_state || !S.use_fast || le - lb < 64) return DG_OK;
-    if (!S.pf_stream) {
-        if (hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.pf_ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError(); S.pf_stream = nullptr; S.l2_prefetch = 0; return DG_OK;       // no side stream: no prefetcher
+    if (!S.pf_stream && hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.pf_stream = nullptr; S.l2_prefetch = 0; return DG_OK; }
+    if (!S.pf_ev && hipEventCreateWithFlags(&S.pf_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.pf_ev = nullptr; S.l2_prefetch = 0; return DG_OK; }
+    // One DP state per process at most: a second instance's sweep could share a hardware queue with THIS state's prefetcher and
+    // would then wait behind it for a whole range (three concurrent instances: 78 -> 52 G cells/s before this rule).
+    if (dp_states_alive().load() > 1) return DG_OK;
+    if (!S.pf_tested) {
+        S.pf_tested = 1;
+        DG_HIP(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(dp_pf_probe_wait_kernel, dim3(1), dim3(1), 0, S.pf_stream, S.d_pfctl.as<PfCtl>(), 0x5EED);
+        hipLaunchKernelGGL(dp_pf_probe_set_kernel, dim3(1), dim3(1), 0, s, S.d_pfctl.as<PfCtl>(), 0x5EED);
+        PfCtl h;
+        if (hipStreamSynchronize(S.pf_stream) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(&h, S.d_pfctl.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess || !h.probe_ok) {
+            (void)hipGetLastError();
+            if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] L2 prefetcher off: its stream does not run beside the sweep's\n");
+            S.l2_prefetch = 0;
+            return DG_OK;
         }
     }
     const int seq = ++S.pf_seq;
