@@ -203,11 +203,15 @@ class ShardedSketch:
             work.wait()
             counts = self._back(counts_c)
             self._lap("fused all_reduce + wait")
-        sizes = tail[:W]
-        base = torch.cumsum(sizes, 0) - sizes            # exclusive scan: first global id of every range
         rank1 = tail[W + HIST_BINS:]
-        ids = torch.where(rank1 > 0, rank1 - 1 + base[owner_t], torch.full_like(rank1, -1))
-        sizes_h = sizes.cpu().tolist()
+        if multi:
+            sizes = tail[:W]
+            base = torch.cumsum(sizes, 0) - sizes        # exclusive scan: first global id of every range
+            ids = torch.where(rank1 > 0, rank1 - 1 + base[owner_t], torch.full_like(rank1, -1))
+            sizes_h = sizes.cpu().tolist()
+        else:                                            # one range: its size is known here, ids are the local ranks
+            ids = rank1 - 1
+            sizes_h = [int(rh.numel())]
         self._lap("ids + host read")
         return Score(counts=counts, ids=ids, n_distinct=int(sum(sizes_h)), hist=tail[W: W + HIST_BINS], range_hash=rh, range_count=rc,
                      range_base=int(sum(sizes_h[:me])), range_sizes=sizes_h)
