@@ -594,7 +594,12 @@ void ExpandedGraph::permute(const std::vector<int32_t> &order) {
 
 void ExpandedGraph::topologically_reorder(int sink) {                  // ExpandedGraph.hpp:29-102
     std::vector<int32_t> indeg(n, 0);
-    for (int32_t d : adj_dst) ++indeg[d];
+    const int64_t n_edges = (int64_t)adj_dst.size();
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n_edges; ++e) {
+#pragma omp atomic
+        ++indeg[adj_dst[e]];
+    }
     std::vector<int32_t> order;                                        // doubles as the FIFO queue
     order.reserve(n);
     for (int32_t v = 0; v < n; ++v) if (indeg[v] == 0 && v != sink) order.push_back(v);   // never push the sink now
@@ -619,34 +624,53 @@ int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // Expand
     auto lap = [&](const char *w) { if (dbg) { double t = now_s(); fprintf(stderr, "[dg::levelize] %-18s %.3f s\n", w, t - tl); tl = t; } };
     const int32_t n0 = n;
     if (n0 == 0) return 0;
-    std::vector<int32_t> indeg(n0, 0);
-    for (int32_t d : adj_dst) ++indeg[d];
     int source = -1;
-    for (int32_t v = 0; v < n0; ++v)
-        if (indeg[v] == 0 && deg(v) > 0) {
-            if (source == -1) source = v;
-            else { std::cout << "Uh oh, multiple potential sources found while leveling\n"; std::exit(-1); }
+    auto take_source = [&](int32_t v) {                                // ExpandedGraph.hpp:283-296: exactly one vertex without in-edges may have out-edges
+        if (source == -1) source = v;
+        else { std::cout << "Uh oh, multiple potential sources found while leveling\n"; std::exit(-1); }
+    };
+    // 1)-3) levels.  The reference seeds lvl with the BFS distance from the source, takes a Kahn order and relaxes
+    // lvl[v] = max(lvl[v], lvl[u] + 1) along it (ExpandedGraph.hpp:300-352).  The fixed point is the longest-path distance
+    // from the source whatever the seed (a vertex's BFS parent already forces lvl >= dist) and whichever topological order is
+    // used; vertices without in-edges stay at 0.  After topologically_reorder every edge goes from a smaller to a larger id,
+    // so the ids themselves are such an order: one pass, no queue, no BFS.  (Any other input takes the literal route.)
+    std::vector<int32_t> lvl(n0, 0);
+    bool sorted = true;
+#pragma omp parallel for schedule(static) reduction(&& : sorted)
+    for (int32_t u = 0; u < n0; ++u)
+        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) sorted = sorted && adj_dst[e] > u;
+    if (sorted) {
+        for (int32_t u = 0; u < n0; ++u) {
+            const int32_t lu = lvl[u] + 1;
+            for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { int32_t &lv = lvl[adj_dst[e]]; if (lv < lu) lv = lu; }
         }
-    if (source < 0 || source >= n0) throw std::runtime_error("bad source index");
-    std::vector<int32_t> dist(n0, -1), q;                              // 1) BFS from the source
-    q.reserve(n0);
-    dist[source] = 0; q.push_back(source);
-    for (size_t h = 0; h < q.size(); ++h) {
-        const int u = q[h];
-        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (dist[v] == -1) { dist[v] = dist[u] + 1; q.push_back(v); } }
+        for (int32_t v = 0; v < n0; ++v) if (lvl[v] == 0 && deg(v) > 0) take_source(v);      // level 0 <=> no in-edge
+        if (source < 0) throw std::runtime_error("bad source index");
+        lap("levels (one pass)");
+    } else {
+        std::vector<int32_t> indeg(n0, 0);
+        for (int32_t d : adj_dst) ++indeg[d];
+        for (int32_t v = 0; v < n0; ++v) if (indeg[v] == 0 && deg(v) > 0) take_source(v);
+        if (source < 0 || source >= n0) throw std::runtime_error("bad source index");
+        std::vector<int32_t> dist(n0, -1), q;                          // 1) BFS from the source
+        q.reserve(n0);
+        dist[source] = 0; q.push_back(source);
+        for (size_t h = 0; h < q.size(); ++h) {
+            const int u = q[h];
+            for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (dist[v] == -1) { dist[v] = dist[u] + 1; q.push_back(v); } }
+        }
+        lap("indeg+bfs");
+        std::vector<int32_t> topo;                                     // 2) Kahn over ALL indeg-0 vertices
+        topo.reserve(n0);
+        for (int32_t v = 0; v < n0; ++v) if (indeg[v] == 0) topo.push_back(v);
+        for (size_t h = 0; h < topo.size(); ++h) {
+            const int u = topo[h];
+            for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) if (--indeg[adj_dst[e]] == 0) topo.push_back(adj_dst[e]);
+        }
+        if ((int32_t)topo.size() != n0) throw std::runtime_error("Graph contains a cycle; strict leveling requires a DAG");
+        for (int32_t v = 0; v < n0; ++v) if (dist[v] >= 0) lvl[v] = dist[v];         // 3) seed / relax
+        for (int u : topo) for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (lvl[v] <= lvl[u]) lvl[v] = lvl[u] + 1; }
     }
-    lap("indeg+bfs");
-    std::vector<int32_t> topo;                                         // 2) Kahn over ALL indeg-0 vertices
-    topo.reserve(n0);
-    for (int32_t v = 0; v < n0; ++v) if (indeg[v] == 0) topo.push_back(v);
-    for (size_t h = 0; h < topo.size(); ++h) {
-        const int u = topo[h];
-        for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) if (--indeg[adj_dst[e]] == 0) topo.push_back(adj_dst[e]);
-    }
-    if ((int32_t)topo.size() != n0) throw std::runtime_error("Graph contains a cycle; strict leveling requires a DAG");
-    std::vector<int32_t> lvl(n0, 0);                                   // 3) seed / relax
-    for (int32_t v = 0; v < n0; ++v) if (dist[v] >= 0) lvl[v] = dist[v];
-    for (int u : topo) for (int64_t e = adj_off[u]; e < adj_off[u + 1]; ++e) { const int v = adj_dst[e]; if (lvl[v] <= lvl[u]) lvl[v] = lvl[u] + 1; }
 
     lap("kahn+relax");
     // 4) dummies for skipped levels: edge (u,v,w) with gap g becomes u -w-> d1 -0-> ... -0-> dg -0-> v; dummy ids are
