@@ -595,10 +595,14 @@ void ExpandedGraph::permute(const std::vector<int32_t> &order) {
 void ExpandedGraph::topologically_reorder(int sink) {                  // ExpandedGraph.hpp:29-102
     std::vector<int32_t> indeg(n, 0);
     const int64_t n_edges = (int64_t)adj_dst.size();
+    if (n_edges < ((int64_t)1 << 26)) {                                // (MHC-24: 0.105 s serial, 0.123 s with atomics; 5 Mbp x 100 walks: 1.07 -> 0.89 s)
+        for (int32_t d : adj_dst) ++indeg[d];
+    } else {
 #pragma omp parallel for schedule(static)
-    for (int64_t e = 0; e < n_edges; ++e) {
+        for (int64_t e = 0; e < n_edges; ++e) {
 #pragma omp atomic
-        ++indeg[adj_dst[e]];
+            ++indeg[adj_dst[e]];
+        }
     }
     std::vector<int32_t> order;                                        // doubles as the FIFO queue
     order.reserve(n);
