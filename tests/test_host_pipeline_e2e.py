@@ -39,6 +39,16 @@ def test_e2e_fast(name, built_cpu, tmp_path):
     check(CASES[name], fa, summ)
 
 
+@pytest.mark.parametrize("name", ["toy2_p2", "bub_e", "bub_c_p1"])
+def test_levelize_literal_route_gives_the_same_output(name, built_cpu, tmp_path, monkeypatch):
+    """strict levelize computes the levels in one pass over the topologically sorted ids; the reference's literal route
+    (BFS seed + Kahn order + relaxation, ExpandedGraph.hpp:300-352) is kept behind DG_LEVELIZE_LITERAL and must produce
+    the same FASTA (= the reference's)"""
+    monkeypatch.setenv("DG_LEVELIZE_LITERAL", "1")
+    fa, summ = run_case(built_cpu, CASES[name], tmp_path)
+    check(CASES[name], fa, summ)
+
+
 @pytest.mark.slow
 def test_e2e_mhc4_diploid(built_cpu, tmp_path):
     # reference: FASTA md5 46394489..., DP value 60729, P1 17 / P2 1 recombinations (SURVEY.md s4)
