@@ -733,19 +733,33 @@ int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // Expand
     n = n1;
 
     lap("dummies");
-    // 5) order by (level, id): stable, so a counting sort by level
+    // 5) order by (level, id): stable, so a counting sort by level -- in parallel: every thread owns a contiguous range of ids,
+    //    counts its vertices per level, and scatters them behind the counts of the threads before it
     int max_level = 0;
+#pragma omp parallel for schedule(static) reduction(max : max_level)
     for (int32_t v = 0; v < n1; ++v) if (level[v] > max_level) max_level = level[v];
-    std::vector<int32_t> width(max_level + 1, 0);
-    for (int32_t v = 0; v < n1; ++v) ++width[level[v]];
-    int max_width = 0;
-    for (int w : width) if (w > max_width) max_width = w;
+    const int NT = std::max(1, std::min(omp_get_max_threads(), 32));
+    const size_t NL = (size_t)max_level + 1;
+    std::vector<int32_t> hist((size_t)NT * NL, 0);
+    auto v_lo = [&](int t) { return (int32_t)((int64_t)n1 * t / NT); };
+#pragma omp parallel for num_threads(NT) schedule(static, 1)
+    for (int t = 0; t < NT; ++t) {
+        int32_t *h = hist.data() + (size_t)t * NL;
+        for (int32_t v = v_lo(t); v < v_lo(t + 1); ++v) ++h[level[v]];
+    }
     level_off.assign(max_level + 2, 0);
-    for (int l = 0; l <= max_level; ++l) level_off[l + 1] = level_off[l] + width[l];
+    int max_width = 0;
+    for (size_t l = 0; l < NL; ++l) {                                   // per level: width, and each thread's first slot
+        int32_t run = level_off[l];
+        for (int t = 0; t < NT; ++t) { const int32_t c = hist[(size_t)t * NL + l]; hist[(size_t)t * NL + l] = run; run += c; }
+        level_off[l + 1] = run;
+        max_width = std::max(max_width, run - level_off[l]);
+    }
     std::vector<int32_t> order(n1);
-    {
-        std::vector<int32_t> fill(level_off.begin(), level_off.end() - 1);
-        for (int32_t v = 0; v < n1; ++v) order[fill[level[v]]++] = v;
+#pragma omp parallel for num_threads(NT) schedule(static, 1)
+    for (int t = 0; t < NT; ++t) {
+        int32_t *fill = hist.data() + (size_t)t * NL;
+        for (int32_t v = v_lo(t); v < v_lo(t + 1); ++v) order[fill[level[v]]++] = v;
     }
     lap("sort");
     permute(order);
