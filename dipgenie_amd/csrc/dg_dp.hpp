@@ -131,6 +131,8 @@ struct DpState {
     hipStream_t pf_stream = nullptr;                    // the ONE side stream: score-delta pieces, then the L2 table prefetcher (dg_dp_sweep.hip)
     hipEvent_t pf_ev = nullptr;
     int pf_seq = 0;
+    bool pf_active = false;                             // a prefetcher accompanies the sweep range being issued
+    int64_t pf_far = 128;                               // pf_far: > 0 = prefetcher blocks also pull the tables pf_far levels ahead into the Infinity Cache (then no periodic look-ahead launches)
     int pf_tested = 0;                                  // 0: the side stream's concurrency with the sweep's stream not yet probed, 1: probed
     mutable int chain_seq = 0;                          // per-launch number of the lean chain walk (ChainSync, dg_dp_trace.hip)
     int64_t use_rowx = 1;                               // rowx: row in-edge matrices (0: every fan-in row fetches its list from in_edge[])

@@ -111,7 +111,7 @@ struct Run {
     int issue_levels(int l0, int l1, int lb, int le) {
         for (int l = l0; l < l1; ++l) {
             if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
-            if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0) {
+            if (S.warm_ahead > 0 && (l - lb) % S.warm_ahead == 0 && (l == lb || !(S.pf_active && S.pf_far > 0))) {
                 // tables of the batch after this one (and, at the start of a range, of this one too)
                 const int q0 = l == lb ? l : (int)std::min<int64_t>(l + S.warm_ahead, le), q1 = (int)std::min<int64_t>(l + 2 * S.warm_ahead, le);
                 if (q1 > q0) sweep_warm_tables(S, X, q0, q1, s);
@@ -394,7 +394,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"digest", &S.want_digest, 0}, {"fast", &S.use_fast, 0}, {"adaptive_rc", &S.adaptive_rc, 0}, {"coop", &S.use_coop, 0},
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
-        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0},
+        {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
         {"host_threads", &S.host_threads, 1},
     };
     for (auto &o : plain)

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
 // the extra launch absorbing the kernel boundary, not the cache.)
 // Hints only: nothing waits for it; it leaves when the host marks the range done, when a newer range's sequence number
 // appears, or after 0.3 ms without progress.
-constexpr int PF_WORKGROUPS = 16;
+constexpr int PF_WORKGROUPS = 16, PF_FAR_WORKGROUPS = 16;
 constexpr unsigned long long PF_IDLE_TICKS = 30000;      // 0.3 ms
 struct PfCtl { int seq, stop, levels_done, probe, probe_ok, pad_[27]; int level; int pad2_[31]; };      // level: a line of its own
 
@@ -538,11 +538,17 @@ __global__ void dp_pf_probe_wait_kernel(PfCtl *c, int token) {
 }
 __global__ void dp_pf_probe_set_kernel(PfCtl *c, int token) { __hip_atomic_store(&c->probe, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__restrict__ descs, FastArgs F, PfCtl *ctl, int seq, int lb, int le, int ahead, int delta_resident) {
+__global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__restrict__ descs, FastArgs F, PfCtl *ctl, int seq, int lb, int le, int ahead_near, int delta_resident, int far) {
     __shared__ int dump[64];
     // a load whose data nobody wants: straight into an LDS dump word per lane (no destination register, nothing to wait for)
 #define DG_DROP_LOAD(PTR) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(PTR), (__attribute__((address_space(3))) void *)dump, 4, 0, 0)
-    const int lane = (int)threadIdx.x, slot = (int)(blockIdx.x >> 3), nslot = (int)(gridDim.x >> 3);
+    // blocks [0, PF_WORKGROUPS): the L2 role (every XCD reads every line of the level `ahead_near` levels down);
+    // blocks beyond (far > 0): the Infinity-Cache role -- each line once chip-wide, `far` levels down (what the periodic
+    // look-ahead launches in the level chain did)
+    const bool far_role = (int)blockIdx.x >= PF_WORKGROUPS;
+    const int lane = (int)threadIdx.x;
+    const int slot = far_role ? (int)blockIdx.x - PF_WORKGROUPS : (int)(blockIdx.x >> 3), nslot = far_role ? (int)gridDim.x - PF_WORKGROUPS : PF_WORKGROUPS >> 3;
+    const int ahead = far_role ? far : ahead_near, behind = far_role ? far - 64 : 0;      // the far role stays within [far - 64, far] levels of the sweep
     int last = INT32_MIN, done = 0;
     unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
     int *level_word = &ctl->level;
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__r
         // that case at well under 1 % of a pass; a longer legitimate gap (the capturing pass) merely ends the prefetching of the range.
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (lv != last) { last = lv; t_last = now; } else if (now - t_last > PF_IDLE_TICKS) break;
-        if (lp <= lv) lp = lv + 1;                                      // overtaken: level lv is running
+        if (lp <= lv + behind) lp = lv + behind + 1;                    // overtaken (L2 role: level lv is running)
         if (lp >= le) break;
         if (lp - lv > ahead) { __builtin_amdgcn_s_sleep(48); continue; }
         const LevelDesc &d = descs[lp];
@@ -578,6 +584,7 @@ __global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__r
         ++lp; ++done;
     }
     if (lane == 0 && blockIdx.x == 0) atomicAdd(&ctl->levels_done, done);
+    (void)far_role;
 #undef DG_DROP_LOAD
 }
 
@@ -725,6 +732,7 @@ void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, h
 
 // L2 prefetcher of the sweep range [lb, le): control words set in stream order on s, the prefetcher itself on the side stream
 int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s) {
+    S.pf_active = false;
     if (S.l2_prefetch <= 0 || !X.small_state || !S.use_fast || le - lb < 64) return DG_OK;
     if (!S.pf_stream && hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.pf_stream = nullptr; S.l2_prefetch = 0; return DG_OK; }
     if (!S.pf_ev && hipEventCreateWithFlags(&S.pf_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.pf_ev = nullptr; S.l2_prefetch = 0; return DG_OK; }
@@ -749,8 +757,10 @@ int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool 
     hipLaunchKernelGGL(dp_pf_ctl_kernel, dim3(1), dim3(1), 0, s, S.d_pfctl.as<PfCtl>(), seq, lb - 1, 0);
     DG_HIP(hipEventRecord(S.pf_ev, s));
     DG_HIP(hipStreamWaitEvent(S.pf_stream, S.pf_ev, 0));
-    hipLaunchKernelGGL(dp_l2_prefetch_kernel, dim3(PF_WORKGROUPS), dim3(64), 0, S.pf_stream, S.d_descs.as<LevelDesc>(), X.F, S.d_pfctl.as<PfCtl>(), seq, lb, le,
-                       (int)S.l2_prefetch, delta_resident ? 1 : 0);
+    const int far = (int)S.pf_far;
+    hipLaunchKernelGGL(dp_l2_prefetch_kernel, dim3(PF_WORKGROUPS + (far > 0 ? PF_FAR_WORKGROUPS : 0)), dim3(64), 0, S.pf_stream, S.d_descs.as<LevelDesc>(), X.F,
+                       S.d_pfctl.as<PfCtl>(), seq, lb, le, (int)S.l2_prefetch, delta_resident ? 1 : 0, far);
+    S.pf_active = true;
     return DG_OK;
 }
 void sweep_prefetch_end(DpState &S, int le, hipStream_t s) {

@@ -98,6 +98,7 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1    lean chain walk where the lattice allows it (next load)
  *   graph_batch n         levels per hipGraph batch (-1: default 1000, 0: plain launches)
  *   l2_prefetch n         levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
+ *   pf_far n              levels ahead at which the prefetcher's far blocks pull tables into the Infinity Cache (0: periodic launches instead)
  *   delta_overlap 0|1|2   score deltas beside the sweep: off / on graphs of >= 32,000 levels / whenever possible (tests)
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
