@@ -59,7 +59,7 @@ SYMBOLS = [
     "dg_dp_set_option", "dg_dp_get_launch_profile", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
-    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid",
+    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid", "dg_dp_get_table_digest",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -78,6 +78,7 @@ lib.dg_dp_solve_diploid.argtypes = [C.c_void_p, C.POINTER(DpGraph), C.POINTER(Dp
 lib.dg_dp_get_level_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 lib.dg_dp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 lib.dg_dp_get_launch_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+lib.dg_dp_get_table_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.dg_sketch_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
 lib.dg_sketch_haplotype.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_int,
@@ -266,6 +267,14 @@ class Context:
         buf = C.create_string_buffer(8192)
         _check(lib.dg_dp_get_launch_profile(self.h, buf, 8192), "dg_dp_get_launch_profile")
         return {k: int(v) for k, v in (item.rsplit(":", 1) for item in buf.value.decode().split())}
+
+    TABLES = ["descs", "in_off", "in_edge", "in_dst", "dtrans", "dblk_first", "grp_begin", "dead_cols", "heavy_rows", "rowrec", "rowx", "slots"]
+
+    def dp_table_digest(self):
+        """{table: FNV-1a digest} of the tables dg_dp_load_graph built for the resident graph"""
+        out = np.zeros(12, np.uint64)
+        _check(lib.dg_dp_get_table_digest(self.h, out.ctypes.data, 12), "dg_dp_get_table_digest")
+        return dict(zip(self.TABLES, (int(x) for x in out)))
 
     def dp_level_digest(self, n_levels):
         out = np.zeros(n_levels, np.uint64)

@@ -63,7 +63,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int64_t rowx_off;
     int32_t rowx_stride;
     int16_t heavy_in[HEAVY_INLINE];                     // the level's first heavy rows (cooperative region: no table lookup)
-    int32_t pad_;
+    int32_t dmax;                                       // largest in-degree among the level's vertices (host: choice of RC)
 };
 
 struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt; };
@@ -115,7 +115,8 @@ struct DpState {
     int64_t use_coop = 1;                               // coop: cooperative tasks for rows with many in-edges (2: whenever possible)
     int64_t max_blocks = 1024;                          // max_blocks: grid of the generic kernel
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
-    int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's table construction
+    int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's host table construction
+    int64_t host_tables = 0;                            // host_tables: 1 = build the tables on the host and upload them (dg_dp_tables.hip; parity twin of dg_dp_build.hip)
     int64_t bp_nt_min_cells = 262144;                   // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
@@ -161,6 +162,7 @@ struct DpState {
     std::vector<int64_t> dblk_first_host;
     int64_t delta_buf_entries = 0;
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
+    int64_t n_grp = 0, n_dead = 0, n_heavy_rows = 0, n_slot_records = 0, n_rowx_words = 0, n_dtrans = 0, n_edges = 0;   // logical table sizes (dg_dp_get_table_digest)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
     DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
 #ifdef DG_SWEEP_PROBE
@@ -206,8 +208,10 @@ struct PoolPause {                       // hipMalloc calls queue behind the one
 void graphs_clear(DpState &S);
 double wall_s();
 
-// ---- table construction + upload (dg_dp_tables.hip) ----
+// ---- table construction (dg_dp_tables.hip: entry, host construction, lattice plan; dg_dp_build.hip: device construction) ----
 int dp_load(dg_ctx *c, const dg_dp_graph *g);
+int dp_build_tables_device(dg_ctx *c, const dg_dp_graph *g, DpState &S, std::vector<int32_t> &dtrans, std::vector<int64_t> &dblk_first, int &max_k);
+int dp_table_digest(dg_ctx *c, uint64_t *out, int n);
 
 // ---- score deltas (dg_dp_delta.hip) ----
 void delta_launch_edge_flags(const DpState &S, hipStream_t s);

@@ -367,6 +367,10 @@ extern "C" int dg_dp_get_level_digest(dg_ctx *c, uint64_t *out, int64_t n) {
     memcpy(out, c->dp->digest_host.data(), 8 * (size_t)n);
     return DG_OK;
 }
+extern "C" int dg_dp_get_table_digest(dg_ctx *c, uint64_t *out, int n) {
+    if (int rc = dgi::bind(c)) return rc;
+    return dgi::dp_table_digest(c, out, n);
+}
 extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
     if (!c || !c->dp || !buf || cap < 2) { dgi::set_error("dg_dp_get_launch_profile: no state"); return DG_ERR_STATE; }
     std::string out;
@@ -395,7 +399,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
-        {"host_threads", &S.host_threads, 1},
+        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0},
     };
     for (auto &o : plain)
         if (!strcmp(key, o.name)) { *o.field = v < o.lo ? o.lo : v; return DG_OK; }

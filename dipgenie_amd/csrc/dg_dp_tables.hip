@@ -1,4 +1,5 @@
-// dg_dp_load_graph: validates the levelized graph, builds the sweep's tables on the host and uploads them.
+// dg_dp_load_graph: validates the levelized graph, gets the sweep's tables built (on the device: dg_dp_build.hip; with option
+// host_tables = 1 on the host, below -- the two must produce the same bytes) and plans the back-pointer lattice.
 //
 //   in-CSR            in-edges of every vertex sorted by (source position asc, adjacency order asc): rank order inside
 //                     a list IS the reference's tie order (pred_i asc / pred_j asc, approximator.cpp:657-659)
@@ -223,6 +224,7 @@ int Builder::build_level_tables() {
             d.n_heavy = (int32_t)P.heavy.size() - d.heavy_first;
             for (int q = 0; q < HEAVY_INLINE; ++q) d.heavy_in[q] = q < d.n_heavy ? (int16_t)P.heavy[(size_t)d.heavy_first + q] : (int16_t)-1;
             S.level_dmax[l] = (int32_t)max_indeg;
+            d.dmax = (int32_t)max_indeg;
             // column groups: greedy runs of whole columns with <= 64 in-edges; a column with more gets its own group
             {
                 uint32_t cur_size = 0;
@@ -514,41 +516,57 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     graphs_clear(S);
     S.loaded = false;
     S.nV = nV; S.L = L; S.R = R; S.RP = R + 1;
-    Builder B(g, S);
-    if (int rc = B.validate_and_index()) return rc;
-    if (int rc = B.build_in_csr()) return rc;
-    lap("validate + in-CSR");
-    if (int rc = B.check_colours()) return rc;
-    lap("colour checks");
-    if (int rc = B.build_level_tables()) return rc;
-    lap("descs + groups + slots");
-    plan_delta_windows(S, B.dtrans, B.dblk_first);
+    hipStream_t s = c->stream;
+    PoolPause pause(S);                                         // the pool thread maps no chunk while this function allocates
+    std::vector<int32_t> dtrans;
+    std::vector<int64_t> dblk_first;
+    int max_k = 1;
+    if (!S.host_tables) {
+        if (int rc = dp_build_tables_device(c, g, S, dtrans, dblk_first, max_k)) return rc;
+    } else {
+        Builder B(g, S);
+        if (int rc = B.validate_and_index()) return rc;
+        if (int rc = B.build_in_csr()) return rc;
+        lap("validate + in-CSR");
+        if (int rc = B.check_colours()) return rc;
+        lap("colour checks");
+        if (int rc = B.build_level_tables()) return rc;
+        lap("descs + groups + slots");
+        if (int rc = upload(S.d_descs, S.descs.data(), sizeof(LevelDesc) * L, s)) return rc;
+        if (int rc = upload(S.d_in_off, B.in_off.data(), 4 * B.in_off.size(), s)) return rc;
+        if (int rc = upload(S.d_in_edge, B.in_edge.data(), 4 * B.in_edge.size(), s)) return rc;
+        if (int rc = upload(S.d_in_dst, B.in_dst.data(), 4 * B.in_dst.size(), s)) return rc;
+        if (int rc = upload(S.d_hom_off, g->hom_off, 8 * ((size_t)nV + 1), s)) return rc;
+        if (int rc = upload(S.d_het_off, g->het_off, 8 * ((size_t)nV + 1), s)) return rc;
+        if (int rc = upload(S.d_hom_col, g->hom_col, 4 * (size_t)g->hom_off[nV], s)) return rc;
+        if (int rc = upload(S.d_het_col, g->het_col, 4 * (size_t)g->het_off[nV], s)) return rc;
+        if (int rc = upload(S.d_dtrans, B.dtrans.data(), 4 * B.dtrans.size(), s)) return rc;
+        if (int rc = upload(S.d_dblk_first, B.dblk_first.data(), 8 * B.dblk_first.size(), s)) return rc;
+        if (int rc = upload(S.d_grp, B.grp_begin.data(), 4 * B.grp_begin.size(), s)) return rc;
+        if (int rc = upload(S.d_dead, B.dead_cols.data(), 4 * B.dead_cols.size(), s)) return rc;
+        if (int rc = upload(S.d_heavy, B.heavy_rows.data(), 4 * B.heavy_rows.size(), s)) return rc;
+        if (int rc = upload(S.d_rowrec, B.rowrec.data(), 4 * B.rowrec.size(), s)) return rc;
+        if (int rc = upload(S.d_rowx, B.rowx.data(), 4 * B.rowx.size(), s)) return rc;
+        if (int rc = upload(S.d_slots, B.slots.data(), 4 * B.slots.size(), s)) return rc;
+        DG_HIP(hipStreamSynchronize(s));                        // the staging vectors die with B
+        S.n_grp = (int64_t)B.grp_begin.size(); S.n_dead = (int64_t)B.dead_cols.size(); S.n_heavy_rows = (int64_t)B.heavy_rows.size() - 1;
+        S.n_slot_records = (int64_t)B.slots.size() / 2; S.n_rowx_words = (int64_t)B.rowx.size() - 4;
+        dtrans.swap(B.dtrans); dblk_first.swap(B.dblk_first);
+        max_k = B.max_k;
+        lap("table uploads");
+    }
+    S.n_dtrans = (int64_t)dtrans.size();
+    S.n_edges = g->out_off[nV];
+    plan_delta_windows(S, dtrans, dblk_first);
+    const size_t n_edges = (size_t)g->out_off[nV];
     const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_buf_entries * 2;
     size_t bp_bytes = 0, ck_bytes = 0;
-    if (int rc = plan_lattice(c, S, st_bytes, dl_bytes, 64 * (size_t)nV + 4 * B.rowx.size(), bp_bytes, ck_bytes, dbg)) return rc;
-    PoolPause pause(S);                                         // until the allocations below are done
+    // (the tables are allocated already; what follows: edge flags + self scores, digests, the path)
+    if (int rc = plan_lattice(c, S, st_bytes, dl_bytes, 3 * n_edges + 16 * (size_t)L + (1 << 20), bp_bytes, ck_bytes, dbg)) return rc;
     lap("plan lattice");
-    hipStream_t s = c->stream;
-    if (int rc = upload(S.d_descs, S.descs.data(), sizeof(LevelDesc) * L, s)) return rc;
-    if (int rc = upload(S.d_in_off, B.in_off.data(), 4 * B.in_off.size(), s)) return rc;
-    if (int rc = upload(S.d_in_edge, B.in_edge.data(), 4 * B.in_edge.size(), s)) return rc;
-    if (int rc = upload(S.d_in_dst, B.in_dst.data(), 4 * B.in_dst.size(), s)) return rc;
-    if (int rc = upload(S.d_hom_off, g->hom_off, 8 * ((size_t)nV + 1), s)) return rc;
-    if (int rc = upload(S.d_het_off, g->het_off, 8 * ((size_t)nV + 1), s)) return rc;
-    if (int rc = upload(S.d_hom_col, g->hom_col, 4 * (size_t)g->hom_off[nV], s)) return rc;
-    if (int rc = upload(S.d_het_col, g->het_col, 4 * (size_t)g->het_off[nV], s)) return rc;
-    if (int rc = upload(S.d_dtrans, B.dtrans.data(), 4 * B.dtrans.size(), s)) return rc;
-    if (int rc = upload(S.d_dblk_first, B.dblk_first.data(), 8 * B.dblk_first.size(), s)) return rc;
-    if (int rc = upload(S.d_grp, B.grp_begin.data(), 4 * B.grp_begin.size(), s)) return rc;
-    if (int rc = upload(S.d_dead, B.dead_cols.data(), 4 * B.dead_cols.size(), s)) return rc;
-    if (int rc = upload(S.d_heavy, B.heavy_rows.data(), 4 * B.heavy_rows.size(), s)) return rc;
-    if (int rc = upload(S.d_rowrec, B.rowrec.data(), 4 * B.rowrec.size(), s)) return rc;
-    if (int rc = upload(S.d_rowx, B.rowx.data(), 4 * B.rowx.size(), s)) return rc;
-    if (int rc = upload(S.d_slots, B.slots.data(), 4 * B.slots.size(), s)) return rc;
-    if (int rc = S.d_eflag.ensure(B.in_dst.size() + 16)) return rc;
-    if (int rc = S.d_eself.ensure(2 * B.in_dst.size() + 16)) return rc;
+    if (int rc = S.d_eflag.ensure(n_edges + 16)) return rc;
+    if (int rc = S.d_eself.ensure(2 * n_edges + 16)) return rc;
     delta_launch_edge_flags(S, s);
-    lap("table uploads");
     if (int rc = S.d_delta.ensure(dl_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_delta.p, 0, 2 * DELTA_PAD, s));
     if (int rc = S.d_ckpt.ensure(ck_bytes)) return rc;
@@ -556,8 +574,8 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (int rc = S.d_pfctl.ensure(256)) return rc;                  // PfCtl of the L2 table prefetcher
     DG_HIP(hipMemsetAsync(S.d_pfctl.p, 0, 256, s));
     DG_HIP(hipMemsetAsync(S.d_chain.p, 0, 128, s)); S.chain_seq = 0;
-    S.pad_front = 2 * (int64_t)B.max_k;
-    const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)B.max_k);
+    S.pad_front = 2 * (int64_t)max_k;
+    const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)max_k);
     if (int rc = S.d_val[0].ensure(st_bytes / 2 + pad_bytes)) return rc;
     if (int rc = S.d_val[1].ensure(st_bytes / 2 + pad_bytes)) return rc;
     DG_HIP(hipMemsetAsync(S.d_val[0].p, 0, S.d_val[0].bytes, s));
@@ -571,14 +589,50 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.cap = 2 * (R + 8);                               // edge records of both paths
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
     if (int rc = S.d_path.ensure(8 * (size_t)L)) return rc;
-    DG_HIP(hipStreamSynchronize(s));      // host staging vectors die here
-    lap("allocs + sync");
+    lap("allocs");
     for (auto &e : S.ev) if (!e) DG_HIP(hipEventCreate(&e));
     memset(&S.timing, 0, sizeof S.timing);
     S.timing.edge_pairs = S.edge_pairs;
     S.timing.colour_entries = S.colour_entries;
     S.timing.state_bytes = st_bytes; S.timing.bp_bytes = bp_bytes; S.timing.delta_bytes = dl_bytes;
     S.loaded = true;
+    return DG_OK;
+}
+
+// FNV-1a over every table of the resident graph (bp_nt is a launch-time field): the device and the host construction must agree
+int dp_table_digest(dg_ctx *c, uint64_t *out, int n) {
+    DpState *Sp = c->dp;
+    if (!Sp || !Sp->loaded) { set_error("dg_dp_get_table_digest: no graph loaded"); return DG_ERR_STATE; }
+    if (!out || n < 12) { set_error("dg_dp_get_table_digest: need 12 words"); return DG_ERR_ARG; }
+    DpState &S = *Sp;
+    DG_HIP(hipStreamSynchronize(c->stream));
+    std::vector<unsigned char> h;
+    auto fnv = [&](const DevBuf &b, size_t bytes, uint64_t &dst) -> int {
+        h.resize(bytes);
+        if (bytes) DG_HIP(hipMemcpy(h.data(), b.p, bytes, hipMemcpyDeviceToHost));
+        uint64_t x = 1469598103934665603ULL;
+        for (size_t i = 0; i < bytes; ++i) { x ^= h[i]; x *= 1099511628211ULL; }
+        dst = x;
+        return DG_OK;
+    };
+    {
+        std::vector<LevelDesc> d(S.L);
+        DG_HIP(hipMemcpy(d.data(), S.d_descs.p, sizeof(LevelDesc) * (size_t)S.L, hipMemcpyDeviceToHost));
+        uint64_t x = 1469598103934665603ULL;
+        for (auto &q : d) { q.bp_nt = 0; const unsigned char *p = (const unsigned char *)&q; for (size_t i = 0; i < sizeof q; ++i) { x ^= p[i]; x *= 1099511628211ULL; } }
+        out[0] = x;
+    }
+    if (int rc = fnv(S.d_in_off, 4 * ((size_t)S.nV + 1), out[1])) return rc;
+    if (int rc = fnv(S.d_in_edge, 4 * (size_t)S.n_edges, out[2])) return rc;
+    if (int rc = fnv(S.d_in_dst, 4 * (size_t)S.n_edges, out[3])) return rc;
+    if (int rc = fnv(S.d_dtrans, 4 * (size_t)S.n_dtrans, out[4])) return rc;
+    if (int rc = fnv(S.d_dblk_first, 8 * (size_t)S.n_dtrans, out[5])) return rc;
+    if (int rc = fnv(S.d_grp, 4 * (size_t)S.n_grp, out[6])) return rc;
+    if (int rc = fnv(S.d_dead, 4 * (size_t)S.n_dead, out[7])) return rc;
+    if (int rc = fnv(S.d_heavy, 4 * (size_t)S.n_heavy_rows, out[8])) return rc;
+    if (int rc = fnv(S.d_rowrec, 16 * (size_t)S.nV, out[9])) return rc;
+    if (int rc = fnv(S.d_rowx, 4 * (size_t)S.n_rowx_words, out[10])) return rc;
+    if (int rc = fnv(S.d_slots, 8 * (size_t)S.n_slot_records, out[11])) return rc;
     return DG_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <iostream>
 #include <string>
 #include <thread>
@@ -24,13 +25,16 @@ struct LazyCtx {
     bool joined = false;
     void start(int device, int k, int w) {
         th = std::thread([this, device, k, w] {
+            const double tc0 = dg::now_s();
             ctx = dg_create(device);
             if (!ctx) { err = dg_last_error(); return; }
+            const double tc1 = dg::now_s();
             // first launch from the sketch module loads its code object and makes the first device allocations (~10 ms):
             // paid here, beside the GFA parse, instead of in front of the first haplotype
             const std::string warm(256, 'A');
             uint64_t *h = nullptr; int64_t *p = nullptr; int64_t n = 0;
             if (k >= 1 && k <= 255 && w >= 1 && dg_sketch_haplotype(ctx, warm.data(), (int64_t)warm.size(), k, w, &h, &p, &n) == DG_OK) { dg_free(h); dg_free(p); }
+            if (getenv("DG_DEBUG")) fprintf(stderr, "[dg::main] side thread: dg_create %.3f s, first sketch call %.3f s\n", tc1 - tc0, dg::now_s() - tc1);
         });
     }
     dg_ctx *get() {
@@ -39,6 +43,26 @@ struct LazyCtx {
     }
 };
 static LazyCtx g_lazy;
+
+// DG_DEBUG timeline: seconds since the kernel started this process (exec, dynamic linking and the HIP library's static
+// initialisers all run before main)
+static double since_exec_s() {
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return -1;
+    char buf[1024];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char *q = strrchr(buf, ')');                      // field 22 (starttime, clock ticks since boot) = 20th after the ')'
+    if (!q) return -1;
+    unsigned long long start = 0;
+    int field = 3;                                          // q + 2 = field 3 (state)
+    for (q += 2; *q && field < 22; ++q) if (*q == ' ') ++field;
+    if (sscanf(q, "%llu", &start) != 1) return -1;
+    struct timespec ts;
+    clock_gettime(CLOCK_BOOTTIME, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec - (double)start / (double)sysconf(_SC_CLK_TCK);
+}
 static const char *b_last_error() { return g_lazy.joined && !g_lazy.ctx ? g_lazy.err.c_str() : dg_last_error(); }
 
 static int b_sketch_reads(void *c, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **cnt, int64_t *nd) {
@@ -96,6 +120,8 @@ int main(int argc, char **argv) {
     // kernel arguments in device memory (the default of this ROCm stack; in host memory every level launch of the sweep
     // costs 1.9 us more: 929 vs 666 ms on MHC-24) -- pinned before the HIP runtime starts
     setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+    const bool dbg_tl = getenv("DG_DEBUG") != nullptr;
+    if (dbg_tl) fprintf(stderr, "[dg::main] main() entered %.3f s after exec\n", since_exec_s());
     dg::Pipeline p;
     int device = 0, help = 0;
     std::string json;
@@ -169,6 +195,7 @@ int main(int argc, char **argv) {
         }
     }
     fprintf(stderr, "[M::main] Real time: %.3f sec\n", dg::now_s() - t0);
+    if (dbg_tl) fprintf(stderr, "[dg::main] leaving %.3f s after exec\n", since_exec_s());
     // Everything is written and closed.  Tearing down tens of GB of device chunks and host vectors one by one costs
     // ~0.4 s that the operating system does for free at exit; DG_CLEAN_EXIT=1 keeps the orderly path (leak checkers).
     if (!getenv("DG_CLEAN_EXIT")) {

@@ -103,8 +103,13 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
  *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
+ *   host_tables 0|1       0 (default): the sweep's tables are built by device kernels from the uploaded graph; 1: on the host, then uploaded (parity twin; next load)
  *   rc_t0_ns, rc_tg_ps, rc_tw_ps, rc_cap, bp_nt_min_cells, max_blocks, host_threads   cost model / launch tuning */
 int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
+/* parity: FNV-1a digests of the 12 tables built by dg_dp_load_graph (level descriptors, in-CSR offsets / sources / destinations,
+ * coloured transitions, their delta blocks, column groups, dead columns, heavy rows, row records, row in-edge matrices, slot
+ * records): the device construction and the host construction (option host_tables) must agree.  out has n >= 12 words. */
+int dg_dp_get_table_digest(dg_ctx *, uint64_t *out, int n);
 /* measurement: which sweep kernel variants the last dg_dp_run launched, as "name:count name:count ..." (the names
  * rocprofv3 reports, abbreviated); lets a profile taken in another process be matched against this run. */
 int dg_dp_get_launch_profile(dg_ctx *, char *buf, int cap);

@@ -131,12 +131,42 @@ def test_dp_random_levelized(gpu_ctx, seed):
     _dp_both(gpu_ctx, g)
 
 
-@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch"])
+def test_dp_device_tables_equal_host_tables(gpu_ctx):
+    """dg_dp_load_graph builds the sweep's tables with device kernels (dg_dp_build.hip); the host construction (option
+    host_tables) is its twin: all twelve tables must come out byte-identical, on narrow / wide / fan-in / colourless / giant-column
+    (in-degree > 64 and > 255) graphs, with and without row in-edge matrices"""
+    cases = [dict(), dict(max_width=30, n_levels=40, R=6), dict(max_width=3, n_levels=200, R=2), dict(R=0), dict(p_colour=0.0),
+             dict(p_colour=1.0, max_list=9, n_colours=10), dict(max_width=70, n_levels=10, R=4, extra_edges=3.0),
+             dict(min_width=1, max_width=1, n_levels=30, R=3), dict(max_width=12, n_levels=1500, R=5, p_colour=0.1), dict(n_levels=2, R=2),
+             dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8), dict(max_width=3, n_levels=8, R=2, extra_edges=100.0),
+             dict(max_width=3, n_levels=6, R=1, extra_edges=300.0, dup_edges=False), dict(min_width=20, max_width=24, n_levels=8, R=2, extra_edges=70.0)]
+    graphs = [graphgen.random_levelized(9100 + q, **kw) for q, kw in enumerate(cases)]
+    graphs += [capi.DpGraphArrays.load(os.path.join(HERE, "golden", n)) for n in ("toy2_R2.dpg", "toy1_k5w3_R2.dpg")]
+    try:
+        for rowx in (1, 0):
+            gpu_ctx.dp_set_option("rowx", rowx)
+            for q, g in enumerate(graphs):
+                gpu_ctx.dp_set_option("host_tables", 1)
+                gpu_ctx.dp_load_graph(g)
+                want = gpu_ctx.dp_table_digest()
+                gpu_ctx.dp_set_option("host_tables", 0)
+                gpu_ctx.dp_load_graph(g)
+                got = gpu_ctx.dp_table_digest()
+                assert got == want, (rowx, q, [t for t in got if got[t] != want[t]])
+                out = gpu_ctx.dp_run()
+                ref = orc.dp_solve(g)
+                assert (out.value, out.s_het, out.p1, out.p2, out.cells, out.relaxations) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"], ref["cells"], ref["relaxations"]), q
+    finally:
+        gpu_ctx.dp_set_option("rowx", 1)
+        gpu_ctx.dp_set_option("host_tables", 0)
+
+
+@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch", "host_tables"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
     """the generic fallback sweep, the fixed-RC launch, cooperative rows off / forced, the path without row in-edge
     matrices and the general chain walk (in place of the lean one) must all give the oracle's answer"""
     opts = {"generic": {"fast": 0}, "no_adaptive": {"adaptive_rc": 0}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}, "no_rowx": {"rowx": 0},
-            "general_chain": {"lean_chain": 0}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}}[mode]
+            "general_chain": {"lean_chain": 0}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}, "host_tables": {"host_tables": 1}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -151,7 +181,7 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
                          (7, dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8)), (8, dict(max_width=70, n_levels=12, R=4, extra_edges=3.0))]:
             _dp_both(gpu_ctx, graphgen.random_levelized(7100 + seed, **kw))
     finally:
-        for k, v in {"fast": 1, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128}.items():
+        for k, v in {"fast": 1, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128, "host_tables": 0}.items():
             gpu_ctx.dp_set_option(k, v)
 
 
