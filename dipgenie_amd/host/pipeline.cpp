@@ -543,22 +543,22 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
 // ======================================================================================
 // ExpandedGraph  (ExpandedGraph.hpp:29-102, 269-409), flat CSR restatement
 // ======================================================================================
-void ExpandedGraph::permute(const std::vector<int32_t> &order) {
+void ExpandedGraph::permute(const uvec<int32_t> &order) {
     // new vertex i = old vertex order[i]; adjacency keeps its per-vertex order (ExpandedGraph.hpp:93-101, 392-400)
     const bool dbg = getenv("DG_DEBUG") != nullptr;
     double tl = now_s();
     auto lap = [&](const char *w) { if (dbg) { double t = now_s(); fprintf(stderr, "[dg::permute] %-18s %.3f s\n", w, t - tl); tl = t; } };
     const int32_t nn = (int32_t)order.size();
-    std::vector<int32_t> new_idx(nn);
+    uvec<int32_t> new_idx(nn);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i) new_idx[order[i]] = i;
-    std::vector<int64_t> noff((size_t)nn + 1, 0);
+    uvec<int64_t> noff((size_t)nn + 1, 0);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i) noff[i + 1] = deg(order[i]);      // (random gathers in parallel, the running sum alone is cheap)
     for (int32_t i = 0; i < nn; ++i) noff[i + 1] += noff[i];
     lap("new_idx+noff");
-    std::vector<int32_t> ndst(adj_dst.size());
-    std::vector<uint8_t> nw(adj_w.size());
+    uvec<int32_t> ndst(adj_dst.size());
+    uvec<uint8_t> nw(adj_w.size());
     lap("alloc");
     // the remap is a random gather (cache-miss bound): spread it over the host threads
 #pragma omp parallel for schedule(static)
@@ -568,23 +568,23 @@ void ExpandedGraph::permute(const std::vector<int32_t> &order) {
     }
     lap("edges");
     adj_off.swap(noff); adj_dst.swap(ndst); adj_w.swap(nw);
-    std::vector<int32_t> nh(nn);
-    std::vector<uint32_t> noo(nn), nol(nn);
+    uvec<int32_t> nh(nn);
+    uvec<uint32_t> noo(nn), nol(nn);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i) { nh[i] = haplotype[order[i]]; noo[i] = orig_off[order[i]]; nol[i] = orig_len[order[i]]; }
     haplotype.swap(nh); orig_off.swap(noo); orig_len.swap(nol);
     if ((int32_t)level.size() == nn) {
-        std::vector<int32_t> nl(nn);
+        uvec<int32_t> nl(nn);
 #pragma omp parallel for schedule(static)
         for (int32_t i = 0; i < nn; ++i) nl[i] = level[order[i]];
         level.swap(nl);
     }
     lap("vertex arrays");
-    std::vector<int64_t> nco((size_t)nn + 1, 0);
+    uvec<int64_t> nco((size_t)nn + 1, 0);
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i) nco[i + 1] = ncol(order[i]);
     for (int32_t i = 0; i < nn; ++i) nco[i + 1] += nco[i];
-    std::vector<int32_t> ncp(col_pool.size());
+    uvec<int32_t> ncp(col_pool.size());
 #pragma omp parallel for schedule(static)
     for (int32_t i = 0; i < nn; ++i)
         std::copy(col_pool.begin() + col_off[order[i]], col_pool.begin() + col_off[order[i] + 1], ncp.begin() + nco[i]);
@@ -604,7 +604,7 @@ void ExpandedGraph::topologically_reorder(int sink) {                  // Expand
             ++indeg[adj_dst[e]];
         }
     }
-    std::vector<int32_t> order;                                        // doubles as the FIFO queue
+    uvec<int32_t> order;                                               // doubles as the FIFO queue
     order.reserve(n);
     for (int32_t v = 0; v < n; ++v) if (indeg[v] == 0 && v != sink) order.push_back(v);   // never push the sink now
     bool sink_ready = (indeg[sink] == 0);
@@ -693,11 +693,11 @@ int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // Expand
     const int64_t n1l = (int64_t)n0 + n_dummy;
     if (n1l >= INT32_MAX) throw std::runtime_error("expanded graph too large");
     const int32_t n1 = (int32_t)n1l;
-    std::vector<int32_t> lv(n1), hp2(n1);
-    std::vector<uint32_t> oo(n1), ol(n1);
-    std::vector<int64_t> noff((size_t)n1 + 1, 0);
-    std::vector<int32_t> ndst((size_t)adj_dst.size() + (size_t)n_dummy);
-    std::vector<uint8_t> nw(ndst.size());
+    uvec<int32_t> lv(n1), hp2(n1);
+    uvec<uint32_t> oo(n1), ol(n1);
+    uvec<int64_t> noff((size_t)n1 + 1, 0);
+    uvec<int32_t> ndst((size_t)adj_dst.size() + (size_t)n_dummy);
+    uvec<uint8_t> nw(ndst.size());
     // old vertices keep their out-degree and edge slots; dummy d (id n0 + d) owns the single slot E + d
     const int64_t E0 = (int64_t)adj_dst.size();
 #pragma omp parallel for schedule(static)
@@ -725,7 +725,7 @@ int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // Expand
     adj_off.swap(noff); adj_dst.swap(ndst); adj_w.swap(nw);
     haplotype.swap(hp2); orig_off.swap(oo); orig_len.swap(ol); level.swap(lv);
     {
-        std::vector<int64_t> nco((size_t)n1 + 1);                      // dummies have no colour
+        uvec<int64_t> nco((size_t)n1 + 1);                             // dummies have no colour
         for (int32_t v = 0; v <= n0; ++v) nco[v] = col_off[v];
         for (int32_t v = n0 + 1; v <= n1; ++v) nco[v] = col_off[n0];
         col_off.swap(nco);
@@ -755,7 +755,7 @@ int ExpandedGraph::strict_bfs_levelize_and_reorder() {                 // Expand
         level_off[l + 1] = run;
         max_width = std::max(max_width, run - level_off[l]);
     }
-    std::vector<int32_t> order(n1);
+    uvec<int32_t> order(n1);
 #pragma omp parallel for num_threads(NT) schedule(static, 1)
     for (int t = 0; t < NT; ++t) {
         int32_t *fill = hist.data() + (size_t)t * NL;
@@ -783,12 +783,14 @@ dg_dp_graph DpGraphStorage::view(int R) const {
 }
 
 namespace {
-template <class T> void wr(std::ofstream &f, const std::vector<T> &v) {
+template <class V> void wr(std::ofstream &f, const V &v) {
+    using T = typename V::value_type;
     uint64_t n = v.size();
     f.write((const char *)&n, 8);
     f.write((const char *)v.data(), (std::streamsize)(n * sizeof(T)));
 }
-template <class T> bool rd(std::ifstream &f, std::vector<T> &v) {
+template <class V> bool rd(std::ifstream &f, V &v) {
+    using T = typename V::value_type;
     uint64_t n = 0;
     if (!f.read((char *)&n, 8)) return false;
     v.resize(n);
@@ -971,6 +973,22 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R, std::string
 // ======================================================================================
 int Pipeline::solve(std::string &err) {
     double t0 = now_s();
+    if (opt.ploidy == 2 && !getenv("DG_GRAPH_LITERAL")) {
+        // the fused route (fast_graph.cpp) covers everything up to the levelized graph; it declines inputs it does not model
+        // (empty walks, several sources, a vertex deeper than the sink ...), which then take the literal route below
+        ExpandedGraph gf;
+        std::vector<std::vector<AnchorRec>> anchorsByHapF;
+        std::vector<uint8_t> color_homo_bv_f;
+        if (build_levelized_fast(gf, anchorsByHapF, color_homo_bv_f)) {
+            stamp("levelized_graph_build", t0);
+            int rc = diploid(gf, color_homo_bv_f, anchorsByHapF, err);
+            if (rc != 0) return rc;
+            if (!opt.quiet) std::cout << "Diploid sequences written to: " << opt.hap_file << std::endl;   // :1330
+            return 0;
+        }
+        sum.n_colours = 0;
+        t0 = now_s();
+    }
     int32_t number_of_vertices = 0;
     for (size_t h = 0; h < paths.size(); h++) number_of_vertices += (int32_t)paths[h].size();
     const int H = (int)paths.size();
@@ -1200,12 +1218,12 @@ int Pipeline::solve(std::string &err) {
 // ======================================================================================
 // diploid_dp_approximation_solver minus the level loop  (approximator.cpp:362-453, 720-1011)
 // ======================================================================================
-int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
+int Pipeline::diploid(ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
                       const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err) {
     double t0 = now_s();
     const int L = (int)g.level_off.size() - 1;
     const int nV = g.n;
-    if (be.hint_dp_soon) {                                             // level widths are final: the exact lattice size
+    if (be.hint_dp_soon && !g.colours_split) {                         // level widths are final: the exact lattice size (the fused route has said so already)
         double cells = 0;
         for (int l = 1; l < L; ++l) { const double kw = (double)(g.level_off[l + 1] - g.level_off[l]); cells += kw * kw; }
         be.hint_dp_soon(be.ctx, (int64_t)std::min(9.0e18, cells * (opt.R + 1)));
@@ -1215,9 +1233,12 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
     // Topology arrays are handed to the device library in place (no copies); only the HOM / HET colour CSR (:431-453,
     // lists are sorted-unique already) is new: counts, prefix sums, fill -- in parallel over vertex blocks.
     dpg = DpGraphStorage();
+    if (!opt.quiet) std::cout << "Creating hetro/hom-zygous colors per vertex lists" << std::endl;
+    if (g.colours_split) {                                             // the fused route wrote the split lists directly
+        dpg.hom_off.swap(g.hom_off); dpg.het_off.swap(g.het_off); dpg.hom_col.swap(g.hom_col); dpg.het_col.swap(g.het_col);
+    } else {
     dpg.hom_off.assign((size_t)nV + 1, 0);
     dpg.het_off.assign((size_t)nV + 1, 0);
-    if (!opt.quiet) std::cout << "Creating hetro/hom-zygous colors per vertex lists" << std::endl;
     for (int c : g.col_pool) (void)color_homo_bv.at(c);                // same out_of_range behaviour as the reference's .at()
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < nV; ++v) {
@@ -1237,14 +1258,15 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
             if (color_homo_bv[c] == 1) dpg.hom_col[ph++] = c; else dpg.het_col[pt++] = c;
         }
     }
+    }
     sum.n_levels = L;
     sum.n_vertices = nV;
     stamp("dp_prologue_flatten", t0);
     if (!opt.dump_prefix.empty()) {                                    // the dump wants the topology too
         dpg.level_off = g.level_off; dpg.out_off = g.adj_off; dpg.out_dst = g.adj_dst; dpg.out_w = g.adj_w;
         dpg.save(opt.dump_prefix + ".dpg", opt.R);
-        std::vector<int32_t>().swap(dpg.level_off); std::vector<int64_t>().swap(dpg.out_off);
-        std::vector<int32_t>().swap(dpg.out_dst); std::vector<uint8_t>().swap(dpg.out_w);
+        uvec<int32_t>().swap(dpg.level_off); uvec<int64_t>().swap(dpg.out_off);
+        uvec<int32_t>().swap(dpg.out_dst); uvec<uint8_t>().swap(dpg.out_w);
     }
     if (opt.dump_only) { err = "dump_only"; return 1; }
 
@@ -1325,7 +1347,7 @@ int Pipeline::diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_
                         if (p_color_freq[which].find(c) == p_color_freq[which].end()) { p_color_freq[which][c] = 1; p_colors[which].push_back(c); }
                         else p_color_freq[which][c] += 1;
                     }
-            if (g.level.at(edge.second) == L - 1) break;
+            if (g.haplotype.at(edge.second), edge.second >= g.level_off[L - 1]) break;   // level[edge.second] == L - 1 (ids are level-sorted)
             const auto &next_edge = wedges.at(i + 1);
             int next_hap = g.haplotype.at(next_edge.first);
             int next_start = find_next_zero_hap(edge.second, next_hap);

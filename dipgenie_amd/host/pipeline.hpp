@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <initializer_list>
@@ -24,6 +25,18 @@
 #include "gfa_reader.hpp"
 
 namespace dg {
+
+// std::vector that leaves trivially-constructible elements uninitialised on resize: the graph arrays hold tens of millions of
+// entries that are all written (in parallel) right after the allocation -- a serial zero fill first costs as much as the fill
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using uvec = std::vector<T, NoInitAlloc<T>>;
 
 struct Backend {     // same signatures as the C ABI, plus an opaque ctx
     void *ctx = nullptr;
@@ -62,21 +75,24 @@ struct Options {
 // parent's list instead of copying it, ExpandedGraph.hpp:330).
 struct ExpandedGraph {
     int32_t n = 0;
-    std::vector<int64_t> adj_off;               // [n+1]
-    std::vector<int32_t> adj_dst;
-    std::vector<uint8_t> adj_w;
-    std::vector<int32_t> haplotype, level;
-    std::vector<uint32_t> orig_off, orig_len;
-    std::vector<int32_t> orig_pool;
-    std::vector<int64_t> col_off;               // [n+1]
-    std::vector<int32_t> col_pool;
-    std::vector<int32_t> level_off;             // [L+1] after levelize (vertex ids are level-sorted)
+    uvec<int64_t> adj_off;                      // [n+1]
+    uvec<int32_t> adj_dst;
+    uvec<uint8_t> adj_w;
+    uvec<int32_t> haplotype, level;             // (level: literal route only; the vertex ids are level-sorted, see level_of)
+    uvec<uint32_t> orig_off, orig_len;
+    uvec<int32_t> orig_pool;
+    uvec<int64_t> col_off;                      // [n+1]  (literal route; the fused route writes the HOM / HET split directly)
+    uvec<int32_t> col_pool;
+    uvec<int32_t> level_off;                    // [L+1] after levelize (vertex ids are level-sorted)
+    bool colours_split = false;                 // hom_* / het_* below are filled (Pipeline::build_levelized_fast)
+    uvec<int64_t> hom_off, het_off;             // [n+1] sorted-unique HOM / HET colour CSR (approximator.cpp:431-453)
+    uvec<int32_t> hom_col, het_col;
     int64_t deg(int v) const { return adj_off[v + 1] - adj_off[v]; }
     int64_t ncol(int v) const { return col_off[v + 1] - col_off[v]; }
     void topologically_reorder(int sink);
     int strict_bfs_levelize_and_reorder();
   private:
-    void permute(const std::vector<int32_t> &order);   // new vertex i = old vertex order[i]
+    void permute(const uvec<int32_t> &order);   // new vertex i = old vertex order[i]
 };
 
 // colour list of an anchor record: nearly always one entry (its own colour), a few more after containment
@@ -111,9 +127,9 @@ struct AnchorRec {            // approximator.h:11-18
 
 // Flattened levelized graph in dg_dp_graph layout (owning storage).
 struct DpGraphStorage {
-    std::vector<int32_t> level_off, out_dst, hom_col, het_col;
-    std::vector<int64_t> out_off, hom_off, het_off;
-    std::vector<uint8_t> out_w;
+    uvec<int32_t> level_off, out_dst, hom_col, het_col;
+    uvec<int64_t> out_off, hom_off, het_off;
+    uvec<uint8_t> out_w;
     dg_dp_graph view(int R) const;
     bool save(const std::string &path, int R) const;   // little-endian binary, see pipeline.cpp
     bool load(const std::string &path, int &R);
@@ -165,8 +181,10 @@ class Pipeline {
   private:
     void read_gfa_from(const GfaGraph &g);
     std::vector<int> haploid_dp(const ExpandedGraph &g, int R, std::string &err);
-    int diploid(const ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
+    int diploid(ExpandedGraph &g, const std::vector<uint8_t> &color_homo_bv,
                 const std::vector<std::vector<AnchorRec>> &anchorsByHap, std::string &err);
+    // fused + threaded route from Anchor_hits to the levelized graph (fast_graph.cpp); false: take the literal route
+    bool build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<AnchorRec>> &anchorsByHap, std::vector<uint8_t> &color_homo_bv);
     void stamp(const char *name, double t0);
 };
 

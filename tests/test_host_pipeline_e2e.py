@@ -45,8 +45,37 @@ def test_levelize_literal_route_gives_the_same_output(name, built_cpu, tmp_path,
     (BFS seed + Kahn order + relaxation, ExpandedGraph.hpp:300-352) is kept behind DG_LEVELIZE_LITERAL and must produce
     the same FASTA (= the reference's)"""
     monkeypatch.setenv("DG_LEVELIZE_LITERAL", "1")
+    monkeypatch.setenv("DG_GRAPH_LITERAL", "1")               # (the fused graph route never reaches the levelizer)
     fa, summ = run_case(built_cpu, CASES[name], tmp_path)
     check(CASES[name], fa, summ)
+
+
+DIPLOID = [n for n in FAST if "-p2" in CASES[n]["args"]]
+
+
+@pytest.mark.parametrize("name", DIPLOID)
+def test_fused_graph_route_equals_literal_route(name, built_cpu, tmp_path):
+    """Pipeline::build_levelized_fast (fused graph construction + Kahn order + levels + dummies + colour split) against the
+    literal route (push log -> CSR -> topologically_reorder -> strict_bfs_levelize_and_reorder -> split), which restates the
+    reference stage by stage: the dumped levelized graphs (.dpg: level offsets, out-CSR with weights, HOM / HET colour CSR)
+    must be identical byte for byte, at 1, 3 and 8 threads, and the literal route still gives the reference's FASTA"""
+    c = CASES[name]
+    base = [built_cpu, "-q"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"])]
+    env_lit = dict(os.environ, DG_GRAPH_LITERAL="1")
+    subprocess.run(base + ["-t4", "-o", str(tmp_path / "lit.fa"), "-D", str(tmp_path / "lit"), "-X"], check=True, env=env_lit,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = open(tmp_path / "lit.dpg", "rb").read()
+    for t in (1, 3, 8):
+        subprocess.run(base + [f"-t{t}", "-o", str(tmp_path / "f.fa"), "-D", str(tmp_path / f"f{t}"), "-X"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert open(tmp_path / f"f{t}.dpg", "rb").read() == want, t
+    env_lit["DG_LEVELIZE_LITERAL"] = ""
+    fa, summ = run_case(built_cpu, c, tmp_path)                # (fused route; test_e2e_fast covers it as well)
+    check(c, fa, summ)
+    out, js = tmp_path / "l.fa", tmp_path / "l.json"
+    subprocess.run(base + ["-t4", "-o", str(out), "-J", str(js)], check=True, env=dict(os.environ, DG_GRAPH_LITERAL="1"),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    check(c, open(out, "rb").read(), json.load(open(js)))
 
 
 @pytest.mark.slow
