@@ -27,7 +27,9 @@ void dp_state_free(DpState *s) {
     delta_overlap_free(*s);
     { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
     if (s->pool.th.joinable()) s->pool.th.join();
+    const double tf0 = wall_s();
     for (void *q : s->pool.chunks) (void)hipFree(q);
+    if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] destroy: %zu lattice chunks freed in %.3f s\n", s->pool.chunks.size(), wall_s() - tf0);
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }

@@ -4,6 +4,7 @@
 // -T -d are honoured; -a -q -N -m -P -H -l -c are accepted and ignored exactly as the reference's DP
 // path ignores them. The two device loops go through libdipgenie_hip.so; there is no
 // CPU fallback: without a usable gfx950 device the program exits with an error.
+#include <sys/resource.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -195,7 +196,12 @@ int main(int argc, char **argv) {
         }
     }
     fprintf(stderr, "[M::main] Real time: %.3f sec\n", dg::now_s() - t0);
-    if (dbg_tl) fprintf(stderr, "[dg::main] leaving %.3f s after exec\n", since_exec_s());
+    if (dbg_tl) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[dg::main] leaving %.3f s after exec; peak RSS %.2f GB, %ld minor page faults, user %.2f s, system %.2f s\n", since_exec_s(),
+                ru.ru_maxrss / 1048576.0, ru.ru_minflt, ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec);
+    }
     // Everything is written and closed.  Tearing down tens of GB of device chunks and host vectors one by one costs
     // ~0.4 s that the operating system does for free at exit; DG_CLEAN_EXIT=1 keeps the orderly path (leak checkers).
     if (!getenv("DG_CLEAN_EXIT")) {
@@ -203,6 +209,9 @@ int main(int argc, char **argv) {
         fflush(nullptr);
         _exit(0);
     }
+    const double td0 = dg::now_s();
     dg_destroy(ctx);
+    if (dbg_tl) fprintf(stderr, "[dg::main] dg_destroy %.3f s\n", dg::now_s() - td0);
+    if (getenv("DG_CLEAN_EXIT_FAST")) { std::cout.flush(); fflush(nullptr); _exit(0); }   // (measurement: device side released, host side left to the OS)
     return 0;
 }
