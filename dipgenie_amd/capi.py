@@ -59,7 +59,7 @@ SYMBOLS = [
     "dg_dp_set_option", "dg_dp_get_launch_profile", "dg_sketch_reads", "dg_sketch_haplotype", "dg_hash_kmers", "dg_free",
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
-    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid", "dg_dp_get_table_digest",
+    "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid", "dg_dp_get_table_digest", "dg_hip_versions", "dg_anchor_add_haplotype_sketched",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -111,7 +111,20 @@ class AnchorResult(C.Structure):
 
 lib.dg_anchor_begin.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int]
 lib.dg_anchor_add_haplotype.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+lib.dg_anchor_add_haplotype_sketched.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
 lib.dg_anchor_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.POINTER(AnchorResult)]
+
+
+lib.dg_hip_versions.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+
+def hip_versions():
+    """(HIP version the library was built against, HIP runtime it is bound to in this process), as "major.minor.patch" strings"""
+    a, b = C.c_int(), C.c_int()
+    if lib.dg_hip_versions(C.byref(a), C.byref(b)) != 0:
+        raise DgError(lib.dg_last_error().decode())
+    fmt = lambda v: f"{v // 10000000}.{v // 100000 % 100}.{v % 100000}"
+    return fmt(a.value), fmt(b.value)
 
 
 class DgError(RuntimeError):

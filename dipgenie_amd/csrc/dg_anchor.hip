@@ -36,7 +36,7 @@ struct HapIndex {                       // one haplotype's minimizers on the dev
 
 struct AnchorState {
     int n_haps = 0, n_vertices = 0, k = 0, w = 0, next_h = 0;
-    DevBuf d_top, d_step_vtx, d_step_start, d_cnt, d_tmp;
+    DevBuf d_top, d_step_vtx, d_step_start, d_cnt, d_tmp, d_imp_hash, d_imp_pos;
     std::vector<HapIndex *> haps;
     ~AnchorState() { for (auto *h : haps) delete h; }
 };
@@ -317,9 +317,11 @@ extern "C" int dg_anchor_begin(dg_ctx *c, int32_t n_haps, int32_t n_vertices, co
     return DG_OK;
 }
 
-extern "C" int dg_anchor_add_haplotype(dg_ctx *c, int32_t h, const char *seq, int64_t len, const int32_t *step_vtx, const int64_t *step_start,
-                                       int64_t n_steps, int64_t *n_minimizers) {
-    if (int rc = bind(c)) return rc;
+// spans of one haplotype's minimizers (device hash / position lists hd, pd) -> its HapIndex
+static int add_haplotype_spans(dg_ctx *c, int32_t h, int64_t len, const uint64_t *hd, const int64_t *pd, int64_t n, const int32_t *step_vtx,
+                               const int64_t *step_start, int64_t n_steps, int64_t *n_minimizers);
+
+static int check_haplotype_args(dg_ctx *c, int32_t h, int64_t len, const int32_t *step_vtx, const int64_t *step_start, int64_t n_steps) {
     if (!c->an) { set_error("dg_anchor_add_haplotype: dg_anchor_begin first"); return DG_ERR_STATE; }
     AnchorState &A = *c->an;
     if (h != A.next_h || h >= A.n_haps) { set_error("dg_anchor_add_haplotype: haplotypes must be added in order (got %d, expected %d)", h, A.next_h); return DG_ERR_ARG; }
@@ -328,9 +330,42 @@ extern "C" int dg_anchor_add_haplotype(dg_ctx *c, int32_t h, const char *seq, in
     }
     for (int64_t q = 0; q < n_steps; ++q)
         if (step_start[q + 1] < step_start[q] || step_vtx[q] < 0 || step_vtx[q] >= A.n_vertices) { set_error("dg_anchor_add_haplotype: bad step %lld", (long long)q); return DG_ERR_ARG; }
-    hipStream_t s = c->stream;
+    return DG_OK;
+}
+
+extern "C" int dg_anchor_add_haplotype(dg_ctx *c, int32_t h, const char *seq, int64_t len, const int32_t *step_vtx, const int64_t *step_start,
+                                       int64_t n_steps, int64_t *n_minimizers) {
+    if (int rc = bind(c)) return rc;
+    if (int rc = check_haplotype_args(c, h, len, step_vtx, step_start, n_steps)) return rc;
     const uint64_t *hd = nullptr; const int64_t *pd = nullptr; int64_t n = 0;
-    if (int rc = sketch_haplotype_dev(c, seq, len, A.k, A.w, &hd, &pd, &n)) return rc;
+    if (int rc = sketch_haplotype_dev(c, seq, len, c->an->k, c->an->w, &hd, &pd, &n)) return rc;
+    return add_haplotype_spans(c, h, len, hd, pd, n, step_vtx, step_start, n_steps, n_minimizers);
+}
+
+// the same for a haplotype whose minimizer list (the output of dg_sketch_haplotype) was computed elsewhere -- by another rank of a
+// haplotype-sharded run (solver.cpp:470-473 runs index_kmers once per haplotype, independently)
+extern "C" int dg_anchor_add_haplotype_sketched(dg_ctx *c, int32_t h, int64_t len, const uint64_t *hash, const int64_t *pos, int64_t n, const int32_t *step_vtx,
+                                                const int64_t *step_start, int64_t n_steps) {
+    if (int rc = bind(c)) return rc;
+    if (int rc = check_haplotype_args(c, h, len, step_vtx, step_start, n_steps)) return rc;
+    if (n < 0 || (n > 0 && (!hash || !pos))) { set_error("dg_anchor_add_haplotype_sketched: null minimizer list"); return DG_ERR_ARG; }
+    for (int64_t q = 0; q < n; ++q)
+        if (pos[q] < 0 || pos[q] + c->an->k > len || (q > 0 && pos[q] < pos[q - 1])) { set_error("dg_anchor_add_haplotype_sketched: bad position at %lld", (long long)q); return DG_ERR_ARG; }
+    AnchorState &A = *c->an;
+    if (int rc = A.d_imp_hash.ensure(8 * (size_t)std::max<int64_t>(n, 1))) return rc;
+    if (int rc = A.d_imp_pos.ensure(8 * (size_t)std::max<int64_t>(n, 1))) return rc;
+    if (n) {
+        DG_HIP(hipMemcpyAsync(A.d_imp_hash.p, hash, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        DG_HIP(hipMemcpyAsync(A.d_imp_pos.p, pos, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    return add_haplotype_spans(c, h, len, A.d_imp_hash.as<uint64_t>(), A.d_imp_pos.as<int64_t>(), n, step_vtx, step_start, n_steps, nullptr);
+}
+
+static int add_haplotype_spans(dg_ctx *c, int32_t h, int64_t len, const uint64_t *hd, const int64_t *pd, int64_t n, const int32_t *step_vtx,
+                               const int64_t *step_start, int64_t n_steps, int64_t *n_minimizers) {
+    (void)h; (void)len;
+    AnchorState &A = *c->an;
+    hipStream_t s = c->stream;
     HapIndex *H = new HapIndex();
     A.haps.push_back(H);
     A.next_h++;

@@ -1,4 +1,5 @@
 // libdipgenie_hip.so -- context management and error plumbing of the C ABI (include/dipgenie_hip.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "dg_internal.hpp"
@@ -44,6 +45,9 @@ extern "C" dg_ctx *dg_create(int device) {
         return nullptr;
     }
     c->own_stream = true;
+    int rt = 0;
+    if (hipRuntimeGetVersion(&rt) == hipSuccess && rt / 100000 != HIP_VERSION / 100000 && getenv("DG_DEBUG"))
+        fprintf(stderr, "[dipgenie_hip] built against HIP %d.%d, running on HIP runtime %d.%d\n", HIP_VERSION / 10000000, HIP_VERSION / 100000 % 100, rt / 10000000, rt / 100000 % 100);
     return c;
 }
 
@@ -82,3 +86,13 @@ extern "C" int dg_device_info(dg_ctx *c, char *name, int cap, int *n_cu, int64_t
 }
 
 extern "C" void dg_free(void *p) { free(p); }
+
+// HIP_VERSION this library was compiled against vs the runtime it is bound to in this process (a Python host that imports torch
+// first runs it on torch's bundled runtime): recorded by bench.py, checked by the GPU tests
+extern "C" int dg_hip_versions(int *compiled, int *runtime) {
+    if (compiled) *compiled = HIP_VERSION;
+    int rt = 0;
+    if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); dgi::set_error("hipRuntimeGetVersion failed"); return DG_ERR_HIP; }
+    if (runtime) *runtime = rt;
+    return DG_OK;
+}

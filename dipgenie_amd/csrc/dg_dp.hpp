@@ -99,11 +99,17 @@ struct FastArgs {                                       // fast sweep kernel
 #endif
 };
 
-inline std::atomic<int> &dp_states_alive() { static std::atomic<int> n{0}; return n; }      // DP states of this process (L2 prefetcher: one at most)
+// DP states alive per device.  The side-stream features (L2 table prefetcher, score deltas beside the sweep) assume that nothing
+// else shares the device's hardware queues with the sweep: with a second state on the SAME device a side-stream kernel of one may
+// sit in front of the other's sweep.  States on other devices do not matter.
+inline std::atomic<int> &dp_states_on_device(int device) { static std::atomic<int> n[64]; return n[device & 63]; }
 
 struct DpState {
-    DpState() { ++dp_states_alive(); }
-    ~DpState() { --dp_states_alive(); }
+    explicit DpState(int dev) : device(dev) { ++dp_states_on_device(device); }
+    ~DpState() { --dp_states_on_device(device); }
+    const int device;
+    int64_t side_stream = -1;                           // side_stream: -1 = on while this is the device's only DP state (and the concurrency probe agrees), 0 = off, 1 = on
+    bool side_stream_ok() const { return side_stream < 0 ? dp_states_on_device(device).load() <= 1 : side_stream != 0; }
     DpState(const DpState &) = delete;
     DpState &operator=(const DpState &) = delete;
     int32_t nV = 0, L = 0, R = 0, RP = 0, cap = 0;
@@ -116,6 +122,7 @@ struct DpState {
     int64_t max_blocks = 1024;                          // max_blocks: grid of the generic kernel
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's host table construction
+    int64_t test_poison_level = 0, test_poison_byte = 0xFF;   // test_poison_*: overwrite one level of the lattice between sweep and walk (tests of the corrupt-lattice path)
     int64_t host_tables = 0;                            // host_tables: 1 = build the tables on the host and upload them (dg_dp_tables.hip; parity twin of dg_dp_build.hip)
     int64_t bp_nt_min_cells = 262144;                   // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
@@ -145,8 +152,9 @@ struct DpState {
     std::vector<int> seg_begin;
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     bool graph_failed = false;                          // capture or instantiation failed once: plain launches from then on
-    std::map<std::tuple<int, int, const void *>, hipGraphExec_t> graphs;   // (first level, end level, biased lattice pointer) -> replayable batch
-    std::map<std::tuple<int, int, const void *>, std::vector<int64_t>> graph_hist;   // ... -> its launches by kernel variant (launch_hist)
+    typedef std::tuple<int, int, const void *, int> GraphKey;     // (first level, end level, biased lattice pointer, look-ahead launches left to the prefetcher)
+    std::map<GraphKey, hipGraphExec_t> graphs;                    // -> replayable batch
+    std::map<GraphKey, std::vector<int64_t>> graph_hist;          // -> its launches by kernel variant (launch_hist)
     bool all_fast = false;
     size_t state_alloc_bytes = 0;
     std::vector<LevelDesc> descs;

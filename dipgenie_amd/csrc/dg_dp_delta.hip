@@ -143,9 +143,9 @@ constexpr int DELTA_PIECES = 8, DELTA_HEAD = 250;
 const uint16_t *delta_launch_overlapped(DpState &S, hipStream_t s) {
     const int nt = (int)S.dtrans_host.size();
     const bool forced = S.delta_overlap == 2;                          // (tests: small graphs too)
-    // (one DP state per process only: with several, a side stream may share a hardware queue with another state's sweep and its pieces
-    // would queue behind whole batches of that sweep)
-    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && (S.L < 32000 || dp_states_alive().load() > 1))) return delta_launch_window(S, 0, s);
+    // (one DP state per device unless option side_stream says otherwise: with several, a side stream may share a hardware queue with
+    // another state's sweep and its pieces would queue behind whole batches of that sweep)
+    if (!S.delta_overlap || nt < 2 * DELTA_PIECES || (!forced && (S.L < 32000 || !S.side_stream_ok()))) return delta_launch_window(S, 0, s);
     const int head = forced ? std::max(2, S.L / 256) : DELTA_HEAD;
     // ONE side stream for these pieces and for the L2 table prefetcher (dg_dp_sweep.hip).  With a stream each, the prefetcher -- a kernel
     // that lives as long as its range's sweep -- and the pieces could meet in one hardware queue (HIP maps streams onto a few of them):

@@ -139,6 +139,9 @@ struct Run {
         X.A.bp = bp_biased; X.F.bp = bp_biased;
         if (int rc = sweep_prefetch_begin(S, X, lb, le, n_win() == 1, s)) return rc;
         const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : 1000;
+        // what issue_levels bakes into a captured batch besides the levels: whether the periodic look-ahead launches are left to the
+        // prefetcher's far blocks -- part of the cache key (a second DP state on the device switches the prefetcher off)
+        const int pf_key = (S.pf_active && S.pf_far > 0) ? 1 : 0;
         for (int l0 = lb; l0 < le;) {
             const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
             const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, le) : le;
@@ -150,7 +153,7 @@ struct Run {
             hipGraphExec_t *slot = nullptr;
             bool capturing = false;
             if (use_graph) {
-                const auto key = std::make_tuple(l0, l1, (const void *)bp_biased);
+                const auto key = std::make_tuple(l0, l1, (const void *)bp_biased, pf_key);
                 slot = &S.graphs[key];
                 if (*slot) {
                     DG_HIP(hipGraphLaunch(*slot, s));
@@ -164,7 +167,16 @@ struct Run {
             }
             const int64_t n_launch_before = n_launch;
             std::vector<int64_t> hist_before(S.launch_hist, S.launch_hist + 64 * 4);
-            if (int rc = issue_levels(l0, l1, lb, le)) return rc;
+            if (int rc = issue_levels(l0, l1, lb, le)) {
+                if (capturing) {                                    // leave the stream usable: end the capture, drop the half-built graph
+                    hipGraph_t cg = nullptr;
+                    (void)hipStreamEndCapture(s, &cg);
+                    if (cg) (void)hipGraphDestroy(cg);
+                    (void)hipGetLastError();
+                    S.graphs.erase(std::make_tuple(l0, l1, (const void *)bp_biased, pf_key));
+                }
+                return rc;
+            }
             if (capturing) {
                 hipGraph_t cg = nullptr;
                 const bool ok = hipStreamEndCapture(s, &cg) == hipSuccess && cg && hipGraphInstantiate(slot, cg, nullptr, nullptr, 0) == hipSuccess;
@@ -175,7 +187,7 @@ struct Run {
                     std::copy(hist_before.begin(), hist_before.end(), S.launch_hist);
                     continue;
                 }
-                std::vector<int64_t> &h = S.graph_hist[std::make_tuple(l0, l1, (const void *)bp_biased)];
+                std::vector<int64_t> &h = S.graph_hist[std::make_tuple(l0, l1, (const void *)bp_biased, pf_key)];
                 h.resize(64 * 4);
                 for (size_t q = 0; q < h.size(); ++q) h[q] = S.launch_hist[q] - hist_before[q];
                 DG_HIP(hipGraphLaunch(*slot, s));
@@ -212,6 +224,11 @@ struct Run {
             host_enqueue_s += wall_s() - th0;
         }
         if (mark_forward_end) DG_HIP(hipEventRecord(S.ev[2], s));
+        if (S.test_poison_level > 0 && S.test_poison_level < S.L)        // tests: a level nobody swept / a damaged lattice
+            for (int ch = c0; ch < c1; ++ch) {
+                const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1], lp = (int)S.test_poison_level;
+                if (lp >= lb && lp < le) DG_HIP(hipMemsetAsync(biased[ch - c0] + S.descs[lp].bp_off, (int)S.test_poison_byte, 2 * (size_t)S.level_units[lp], s));
+            }
         for (int ch = c1 - 1; ch >= c0; --ch) {
             const int lb = S.d_bp.p ? 1 : S.chunk_begin[ch], le = S.d_bp.p ? S.L : S.chunk_begin[ch + 1];
             trace_launch_warm_rows(S, lb, le, s);
@@ -345,7 +362,7 @@ extern "C" int dg_dp_solve_diploid(dg_ctx *c, const dg_dp_graph *g, dg_dp_result
 }
 extern "C" int dg_dp_prealloc(dg_ctx *c, int64_t bytes) {
     if (int rc = dgi::bind(c)) return rc;
-    if (!c->dp) c->dp = new dgi::DpState();
+    if (!c->dp) c->dp = new dgi::DpState(c->device);
     dgi::DpState &S = *c->dp;
     if (S.pool.chunk_units != S.chunk_units_cfg) { dgi::pool_clear(S); S.pool.chunk_units = S.chunk_units_cfg; }
     const size_t chunk_bytes = S.pool.chunk_units * 2;
@@ -393,7 +410,7 @@ extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
 // graph_batch, warm_ahead), profiler aid (sync_every), tuning (rc_*, bp_nt_min_cells, max_blocks, host_threads).
 extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
     if (!c || !key) { dgi::set_error("dg_dp_set_option: null"); return DG_ERR_ARG; }
-    if (!c->dp) c->dp = new dgi::DpState();
+    if (!c->dp) c->dp = new dgi::DpState(c->device);
     dgi::DpState &S = *c->dp;
     dgi::graphs_clear(S);
     struct { const char *name; int64_t *field; int64_t lo; } plain[] = {
@@ -401,7 +418,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
-        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0},
+        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1}, {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
     };
     for (auto &o : plain)
         if (!strcmp(key, o.name)) { *o.field = v < o.lo ? o.lo : v; return DG_OK; }

@@ -736,9 +736,10 @@ int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool 
     if (S.l2_prefetch <= 0 || !X.small_state || !S.use_fast || le - lb < 64) return DG_OK;
     if (!S.pf_stream && hipStreamCreateWithFlags(&S.pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); S.pf_stream = nullptr; S.l2_prefetch = 0; return DG_OK; }
     if (!S.pf_ev && hipEventCreateWithFlags(&S.pf_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); S.pf_ev = nullptr; S.l2_prefetch = 0; return DG_OK; }
-    // One DP state per process at most: a second instance's sweep could share a hardware queue with THIS state's prefetcher and
-    // would then wait behind it for a whole range (three concurrent instances: 78 -> 52 G cells/s before this rule).
-    if (dp_states_alive().load() > 1) return DG_OK;
+    // One DP state per DEVICE (option side_stream: -1 = this rule, 0 / 1 = the caller decides): a second instance's sweep could share a
+    // hardware queue with THIS state's prefetcher and would then wait behind it for a whole range (three concurrent instances on
+    // one GPU: 78 -> 52 G cells/s before this rule).
+    if (!S.side_stream_ok()) return DG_OK;
     if (!S.pf_tested) {
         S.pf_tested = 1;
         DG_HIP(hipStreamSynchronize(s));

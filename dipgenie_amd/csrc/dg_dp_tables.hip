@@ -511,7 +511,7 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     if (nV < 2 || L < 2 || R < 0 || R > 4096) { set_error("dg_dp_load_graph: bad sizes (V=%d L=%d R=%d)", nV, L, R); return DG_ERR_ARG; }
     if (g->level_off[0] != 0 || g->level_off[L] != nV) { set_error("level_off must span [0, n_vertices]"); return DG_ERR_ARG; }
     if (g->level_off[1] != 1) { set_error("level 0 must hold exactly the source vertex"); return DG_ERR_ARG; }
-    if (!c->dp) c->dp = new DpState();
+    if (!c->dp) c->dp = new DpState(c->device);
     DpState &S = *c->dp;
     graphs_clear(S);
     S.loaded = false;

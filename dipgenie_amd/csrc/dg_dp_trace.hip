@@ -379,7 +379,9 @@ __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *_
         const int pi = (int)(b.x & 0x7FFFu), pj = (int)(b.y & 0x7FFFu);
         const int wu = (int)(b.x >> 31), wv = (int)(b.y >> 31);
         const LevelDesc d = descs[l];
-        if (pi >= d.k || pj >= d.k) { out->corrupt = 1; continue; }  // a hop that leaves its source level (the lean walk does not check per step)
+        // a hop that leaves its level (the lean walk does not check per step): the source ids of this level's hop AND the destination
+        // ids taken from the hop recorded one level up, before either indexes a colour list
+        if (pi >= d.k || pj >= d.k || i >= d.k2 || j >= d.k2) { out->corrupt = 1; continue; }
         const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
         if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
         const int reps = (l == L - 1) ? 1 : 0;

@@ -139,11 +139,12 @@ class ShardedSketch:
     def _dictionary_ranges(self, dict_t):
         """[lo, hi) = the slice of the sorted dictionary inside this rank's hash range, and the owner of every dictionary
         hash; a function of (dictionary, world) only: computed once and kept"""
-        key = (dict_t.data_ptr(), dict_t.numel(), self.world)
-        if getattr(self, "_dict_key", None) != key:
+        # keyed on the tensor OBJECT (kept alive here, so its address cannot be handed to another dictionary) and its version
+        # counter (in-place edits): an address + length key would silently serve a stale slice to an equally long new tensor
+        if getattr(self, "_dict_ref", None) is not dict_t or self._dict_ver != (dict_t._version, self.world):
             split = self.ops.partition(dict_t, self.world).cpu().tolist()
             self._dict_cache = (int(split[self.rank]), int(split[self.rank + 1]), hash_owner(dict_t, self.world))
-            self._dict_key = key
+            self._dict_ref, self._dict_ver = dict_t, (dict_t._version, self.world)
         return self._dict_cache
 
     def _lap(self, name):

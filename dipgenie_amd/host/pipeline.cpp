@@ -151,6 +151,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     // (dg_anchor_*) and later returns the finished occurrence list; the host path below does the same with the
     // position lists of be.sketch_haplotype.  Both end in the same `occs` / `vpool` (tests/golden/anchors.json).
     bool dev_anchors = be.anchor_begin && be.anchor_add_haplotype && be.anchor_finish && !opt.host_anchors;
+    for (const HapSketch &hs : inj_hap) if (hs.set && !be.anchor_add_haplotype_sketched) dev_anchors = false;   // (a backend without the import: host index)
     auto host_index = [&]() {
     // The backend calls are issued by one thread, back to back (a ctx is not thread-safe); the position -> vertex-span
     // mapping of a finished haplotype (:343-357) runs as a task on the other threads meanwhile.
@@ -169,7 +170,15 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
         }
         uint64_t *hh = nullptr; int64_t *pp = nullptr; int64_t n = 0;
         const double ts0 = now_s();
-        int rc = be.sketch_haplotype(be.ctx, hap.data(), (int64_t)hap.size(), k, opt.w, &hh, &pp, &n);
+        int rc = 0;
+        if (h < inj_hap.size() && inj_hap[h].set) {                    // sketched by another rank: same (malloc'ed) hand-off as the backend's
+            n = (int64_t)inj_hap[h].hash.size();
+            hh = (uint64_t *)malloc(8 * (size_t)(n + 1)); pp = (int64_t *)malloc(8 * (size_t)(n + 1));
+            std::copy(inj_hap[h].hash.begin(), inj_hap[h].hash.end(), hh);
+            std::copy(inj_hap[h].pos.begin(), inj_hap[h].pos.end(), pp);
+        } else {
+            rc = be.sketch_haplotype(be.ctx, hap.data(), (int64_t)hap.size(), k, opt.w, &hh, &pp, &n);
+        }
         t_sketch += now_s() - ts0;
         if (rc != 0) {
             rc_sketch = rc;
@@ -205,7 +214,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
                 ix.v.insert(ix.v.end(), uniq.begin(), uniq.end());
                 ix.voff.push_back((uint32_t)ix.v.size());
             }
-            be.free_buf(hh); be.free_buf(pp);
+            if (h < inj_hap.size() && inj_hap[h].set) { free(hh); free(pp); } else { be.free_buf(hh); be.free_buf(pp); }
             delete seg_start_p;
         }
     }
@@ -224,11 +233,17 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             size_t tot = 0;
             for (size_t i = 0; i < ns; ++i) { seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
             seg_start[ns] = (int64_t)tot;
-            hap.clear(); hap.reserve(tot);
-            for (size_t i = 0; i < ns; ++i) hap += node_seq[paths[h][i]];
+            hap.clear();
+            if (!(h < inj_hap.size() && inj_hap[h].set)) { hap.reserve(tot); for (size_t i = 0; i < ns; ++i) hap += node_seq[paths[h][i]]; }
             int64_t n = 0;
             const double ts0 = now_s();
-            if (be.anchor_add_haplotype(be.ctx, (int32_t)h, hap.data(), (int64_t)hap.size(), step_vtx.data(), seg_start.data(), (int64_t)ns, &n) != 0) {
+            if (h < inj_hap.size() && inj_hap[h].set) {                // sketched by another rank
+                n = (int64_t)inj_hap[h].hash.size();
+                if (be.anchor_add_haplotype_sketched(be.ctx, (int32_t)h, (int64_t)tot, inj_hap[h].hash.data(), inj_hap[h].pos.data(), n, step_vtx.data(),
+                                                     seg_start.data(), (int64_t)ns) != 0) {
+                    err = std::string("anchor_add_haplotype_sketched failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
+                }
+            } else if (be.anchor_add_haplotype(be.ctx, (int32_t)h, hap.data(), (int64_t)hap.size(), step_vtx.data(), seg_start.data(), (int64_t)ns, &n) != 0) {
                 err = std::string("anchor_add_haplotype failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
             }
             t_sketch += now_s() - ts0;
@@ -249,7 +264,12 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     t0 = now_s();
     std::vector<uint64_t> sp_hash;     // sorted distinct read-minimizer hashes; id = rank (:541-546)
     std::vector<int32_t> sp_count;     // number of reads containing it (== kmer_count)
-    {
+    if (spectrum_injected) {                                           // the read-sharded ranks' merged spectrum (dist_sketch.py)
+        for (size_t q = 1; q < inj_sp_hash.size(); ++q)
+            if (inj_sp_hash[q] <= inj_sp_hash[q - 1]) { err = "injected spectrum: hashes must be strictly ascending"; return -1; }
+        if (inj_sp_count.size() != inj_sp_hash.size()) { err = "injected spectrum: one count per hash"; return -1; }
+        sp_hash = inj_sp_hash; sp_count = inj_sp_count;
+    } else {
         std::vector<int64_t> off(reads.size() + 1, 0);
         for (size_t r = 0; r < reads.size(); ++r) off[r + 1] = off[r] + (int64_t)reads[r].second.size();
         std::string bases;
@@ -511,6 +531,11 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     t0 = now_s();
     std::map<int32_t, int32_t> kmer_freq;                              // :745-750
     for (int32_t c : sp_count) kmer_freq[c] += 1;
+    if (spectrum_injected && !inj_hist.empty()) {                      // the ranks' all-reduced Hist_kmer must be the histogram of the counts they sent
+        std::vector<int64_t> mine(inj_hist.size(), 0);
+        for (auto &kv : kmer_freq) mine[std::min<size_t>((size_t)std::max(kv.first, 0), mine.size() - 1)] += kv.second;
+        if (mine != inj_hist) { err = "injected multiplicity histogram does not match the injected counts"; return -1; }
+    }
     std::vector<HistBin> hist;
     int max_mult = 0;
     for (auto &kv : kmer_freq) { hist.push_back({(int)kv.first, (double)kv.second}); max_mult = std::max(max_mult, (int)kv.first); }
@@ -1430,13 +1455,31 @@ int Pipeline::run(std::string &err) {                                  // main.c
 #ifdef _OPENMP
     omp_set_num_threads(opt.threads);
 #endif
-    double t0 = now_s();
+    t_run0 = now_s();
     if (load_graph(err)) return -1;
+    return run_loaded(err);
+}
+
+std::string Pipeline::haplotype_sequence(uint32_t h) const {           // solver.cpp:283-288
+    std::string hap;
+    size_t tot = 0;
+    for (uint32_t v : paths.at(h)) tot += node_seq[v].size();
+    hap.reserve(tot);
+    for (uint32_t v : paths[h]) hap += node_seq[v];
+    return hap;
+}
+
+int Pipeline::run_loaded(std::string &err) {                           // main.cpp:163-165
+    opt.threads = std::max(1, opt.threads);
+#ifdef _OPENMP
+    omp_set_num_threads(opt.threads);
+#endif
+    const double t0 = t_run0 > 0 ? t_run0 : now_s();
     if (opt.ploidy != 1 && opt.ploidy != 2) {
         std::cout << "Current approximator support is only for ploidy = 1 or ploidy = 2" << std::endl;
         return 0;
     }
-    if (load_reads(err)) return -1;
+    if (!spectrum_injected && load_reads(err)) return -1;
     if (compute_and_classify_anchors(err)) return -1;
     if (!opt.anchor_dump.empty()) {
         if (!dump_anchors(opt.anchor_dump)) { err = "cannot write " + opt.anchor_dump; return -1; }

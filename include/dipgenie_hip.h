@@ -48,6 +48,7 @@ const char *dg_last_error(void);                   /* thread-local message of th
 int         dg_set_stream(dg_ctx *, void *hip_stream);   /* adopt an external hipStream_t (e.g. torch's) */
 int         dg_synchronize(dg_ctx *);
 int         dg_device_info(dg_ctx *, char *name, int name_cap, int *n_cu, int64_t *hbm_bytes);
+int         dg_hip_versions(int *compiled, int *runtime);   /* HIP_VERSION of the build / of the runtime bound in this process (major * 10^7 + minor * 10^5 + patch) */
 
 /* ---- diploid pair-of-paths DP ---- */
 typedef struct dg_dp_graph {          /* levelized expanded graph, vertex ids already level-sorted */
@@ -103,6 +104,8 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
  *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
+ *   side_stream -1|0|1    L2 prefetcher + score deltas beside the sweep: -1 (default) while this is the only DP state on its device, 0 never, 1 always
+ *   test_poison_level l, test_poison_byte b   tests: fill level l of the back-pointer lattice with byte b between sweep and walk (dg_dp_run must answer DG_ERR_STATE)
  *   host_tables 0|1       0 (default): the sweep's tables are built by device kernels from the uploaded graph; 1: on the host, then uploaded (parity twin; next load)
  *   rc_t0_ns, rc_tg_ps, rc_tw_ps, rc_cap, bp_nt_min_cells, max_blocks, host_threads   cost model / launch tuning */
 int dg_dp_set_option(dg_ctx *, const char *key, int64_t value);
@@ -185,6 +188,11 @@ int dg_anchor_begin(dg_ctx *, int32_t n_haps, int32_t n_vertices, const int32_t 
  * step_start[n_steps + 1] = base offset of every step (step_start[n_steps] = len).  *n_minimizers = |index_kmers(h)|. */
 int dg_anchor_add_haplotype(dg_ctx *, int32_t h, const char *seq, int64_t len, const int32_t *step_vtx, const int64_t *step_start,
                             int64_t n_steps, int64_t *n_minimizers);
+/* the same for a haplotype whose minimizer list (hash / pos = the output of dg_sketch_haplotype on its sequence, host memory) was
+ * computed elsewhere: in a haplotype-sharded run every rank sketches its share of the haplotypes (src/solver.cpp:470-473 runs
+ * index_kmers once per haplotype, independently) and the rank that owns the anchor stage imports them. */
+int dg_anchor_add_haplotype_sketched(dg_ctx *, int32_t h, int64_t len, const uint64_t *hash, const int64_t *pos, int64_t n,
+                                     const int32_t *step_vtx, const int64_t *step_start, int64_t n_steps);
 typedef struct dg_anchor_result {     /* Anchor_hits flattened: occurrence i = (occ_id[i], occ_hap[i], vpool[occ_off[i] .. +occ_len[i])), */
     int64_t n_occ, n_vtx;             /* in Anchor_hits order (id asc, haplotype asc, occurrence order of :641-663)                     */
     int32_t *occ_id, *occ_hap;        /* malloc'ed by the library: dg_free each                                                         */

