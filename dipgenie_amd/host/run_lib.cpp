@@ -24,6 +24,8 @@ struct dgr_handle {
     dg::Pipeline p;
     std::string hap_buf;
     int32_t hap_buf_h = -1;
+    std::string read_bases;
+    std::vector<int64_t> read_off;
     void *ctx = nullptr;              // dg_ctx (HIP backend)
     int device = 0;
 };
@@ -89,6 +91,22 @@ extern "C" int dgr_haplotype_sequence(dgr_handle *H, int32_t h, const char **seq
     if (!H || !seq || !len || h < 0 || h >= (int32_t)H->p.num_walks) return fail("dgr_haplotype_sequence: bad arguments");
     if (H->hap_buf_h != h) { H->hap_buf = H->p.haplotype_sequence((uint32_t)h); H->hap_buf_h = h; }
     *seq = H->hap_buf.data(); *len = (int64_t)H->hap_buf.size();
+    return 0;
+}
+
+extern "C" int dgr_load_reads(dgr_handle *H, int64_t *n_reads, const char **bases, const int64_t **read_off) {
+    if (!H || !n_reads || !bases || !read_off) return fail("dgr_load_reads: bad arguments");
+    if (H->p.opt.reads_file.empty()) return fail("dgr_load_reads: no reads file");
+    if (H->read_off.empty()) {
+        std::string err;
+        if (H->p.load_reads(err) != 0) return fail("dgr_load_reads: " + err);
+        H->read_off.assign(H->p.reads.size() + 1, 0);
+        for (size_t r = 0; r < H->p.reads.size(); ++r) H->read_off[r + 1] = H->read_off[r] + (int64_t)H->p.reads[r].second.size();
+        H->read_bases.reserve((size_t)H->read_off.back());
+        for (auto &rd : H->p.reads) H->read_bases += rd.second;
+        H->p.reads.clear(); H->p.reads.shrink_to_fit();
+    }
+    *n_reads = (int64_t)H->read_off.size() - 1; *bases = H->read_bases.data(); *read_off = H->read_off.data();
     return 0;
 }
 

@@ -45,6 +45,9 @@ const char *dgr_last_error(void);
 int32_t     dgr_n_haplotypes(dgr_handle *);
 /* *seq points into the handle (valid until the next call for another haplotype or dgr_close) */
 int dgr_haplotype_sequence(dgr_handle *, int32_t h, const char **seq, int64_t *len);
+/* Solver::read_ip_reads (src/solver.cpp:230-245) on options.reads_file: all reads concatenated + offsets [n + 1]; the arrays live in
+ * the handle.  A sharded run hands every rank its contiguous block of them. */
+int dgr_load_reads(dgr_handle *, int64_t *n_reads, const char **bases, const int64_t **read_off);
 int dgr_inject_haplotype_sketch(dgr_handle *, int32_t h, const uint64_t *hash, const int64_t *pos, int64_t n);
 /* hist may be NULL; otherwise hist[min(count, n_bins - 1)] = #distinct hashes with that count */
 int dgr_inject_spectrum(dgr_handle *, const uint64_t *sp_hash, const int32_t *sp_count, int64_t n, const int64_t *hist, int32_t n_bins);
