@@ -44,7 +44,7 @@ class DpTiming(C.Structure):
     _fields_ = [
         ("delta_ms", C.c_float), ("forward_ms", C.c_float), ("traceback_ms", C.c_float), ("total_ms", C.c_float),
         ("n_forward_launches", C.c_int64), ("edge_pairs", C.c_uint64), ("colour_entries", C.c_uint64),
-        ("state_bytes", C.c_uint64), ("bp_bytes", C.c_uint64), ("delta_bytes", C.c_uint64),
+        ("state_bytes", C.c_uint64), ("bp_bytes", C.c_uint64), ("delta_bytes", C.c_uint64), ("n_segments", C.c_int32), ("n_chunks", C.c_int32),
     ]
 
 

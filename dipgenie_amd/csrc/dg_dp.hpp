@@ -66,7 +66,7 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t dmax;                                       // largest in-degree among the level's vertices (host: choice of RC)
 };
 
-struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt; };
+struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt, path_score; };   // path_score: sum of the score deltas along the walked path (must equal value)
 struct ChainState { int32_t i, j, r, value; };
 struct ColourCsr { const int64_t *hom_off, *het_off; const int32_t *hom_col, *het_col; };
 

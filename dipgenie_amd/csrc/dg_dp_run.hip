@@ -328,7 +328,12 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     DG_HIP(hipEventElapsedTime(&S.timing.traceback_ms, S.ev[2], S.ev[3]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[3]));
     S.timing.n_forward_launches = run.n_launch;
+    S.timing.n_segments = (int32_t)S.seg_begin.size() - 1;
+    S.timing.n_chunks = (int32_t)S.chunk_begin.size() - 1;
     if (to.value == CHAIN_CORRUPT || to.corrupt) { set_error("back-pointer lattice is corrupt: the chain walk left its level (a level was not swept?)"); return DG_ERR_STATE; }
+    if (to.value != NEG_INF && to.path_score != to.value) {
+        set_error("traceback path scores %d but the DP value is %d: sweep, lattice and walk disagree", to.path_score, to.value); return DG_ERR_STATE;
+    }
     if (to.overflow || to.n_e > S.cap) { set_error("traceback edge list overflow (%d > %d)", to.n_e, S.cap); return DG_ERR_STATE; }
     res->value = to.value; res->s_het = to.s_het;
     res->cells = S.cells; res->relaxations = S.relaxations;

@@ -452,6 +452,10 @@ int plan_lattice(dg_ctx *c, DpState &S, size_t st_bytes, size_t dl_bytes, size_t
     int64_t ckpt_cells = 0;
     if (segmented) {
         group = S.segment_cells > 0 ? 1 : std::max<size_t>(1, std::min(n_chunks - 1, (have - fixed) / chunk_bytes));
+        // Beyond HBM every level is swept twice whatever the segment size, but a segment's chunks must be mapped before its re-sweep
+        // starts and mapping runs at ~85 GB/s (the 5 Mbp x 100-walk panel waited 3.5 s for 33 chunks = all of HBM): stay near what
+        // the background thread has mapped by now -- more, smaller segments cost one tiny checkpoint each
+        if (S.segment_cells == 0) group = std::min(group, std::max<size_t>(8, pool_bytes / chunk_bytes + 2));
         for (;; --group) {
             S.seg_begin.assign(1, 1);
             S.ckpt_off.assign(1, 0);

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *_
     const int value = st->value;
     if (blockIdx.x == 0 && threadIdx.x == 0) out->value = value;
     if (value == NEG_INF || value == CHAIN_CORRUPT) return;
-    int shet = 0;
+    int shet = 0, sinter = 0;
     for (int l = 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x); l < L; l += (int)(gridDim.x * blockDim.x)) {
         const uint2 b = path[l];
         int i = 0, j = 0;                                             // destination cell at level l = predecessor recorded at l+1
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *_
         // ids taken from the hop recorded one level up, before either indexes a colour list
         if (pi >= d.k || pj >= d.k || i >= d.k2 || j >= d.k2) { out->corrupt = 1; continue; }
         const int u1 = d.a0 + pi, v1 = d.a0 + pj, u2 = d.b0 + i, v2 = d.b0 + j;
-        if (d.delta_off >= 0) shet += score_symd(col, u1, v1, u2, v2);
+        if (d.delta_off >= 0) { shet += score_symd(col, u1, v1, u2, v2); sinter += score_inter(col, u1, v1, u2, v2); }
         const int reps = (l == L - 1) ? 1 : 0;
         for (int q = 0; q < reps + wu; ++q) {
             const int e = atomicAdd(&out->n_e, 1);
@@ -394,8 +394,11 @@ __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *_
             if (e < cap_e) { edges[e] = l; edges[cap_e + e] = v1; edges[2 * cap_e + e] = v2; edges[3 * cap_e + e] = 1; }
         }
     }
-    for (int sft = 32; sft > 0; sft >>= 1) shet += __shfl_down(shet, sft);
+    // the walked path re-scored from the colour lists (approximator.cpp:614-618): its total must be the DP value -- a check of the
+    // whole chain sweep -> lattice -> walk on every run
+    for (int sft = 32; sft > 0; sft >>= 1) { shet += __shfl_down(shet, sft); sinter += __shfl_down(sinter, sft); }
     if ((threadIdx.x & 63) == 0 && shet) atomicAdd(&out->s_het, shet);
+    if ((threadIdx.x & 63) == 0 && (shet | sinter)) atomicAdd(&out->path_score, shet + sinter);
 }
 
 void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {   // row records of destination levels [lb, le), at most ~200 MB worth

@@ -76,7 +76,20 @@ static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint6
 }
 static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) {
     dg_ctx *x = ((LazyCtx *)c)->get();
-    return x ? dg_dp_solve_diploid(x, g, r) : DG_ERR_NO_DEVICE;
+    if (!x) return DG_ERR_NO_DEVICE;
+    // DG_DP_OPTIONS="key=value,key=value": dg_dp_set_option knobs for experiments and the segmented-lattice tests (none needed in normal use)
+    if (const char *o = getenv("DG_DP_OPTIONS")) {
+        std::string all(o);
+        for (size_t a = 0; a < all.size();) {
+            size_t b = all.find(',', a);
+            if (b == std::string::npos) b = all.size();
+            const std::string kv = all.substr(a, b - a);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos && dg_dp_set_option(x, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != DG_OK) return DG_ERR_ARG;
+            a = b + 1;
+        }
+    }
+    return dg_dp_solve_diploid(x, g, r);
 }
 static int b_hap(void *c, const dg_hap_graph *g, int32_t *dp, int32_t *bv, int32_t *br) {
     dg_ctx *x = ((LazyCtx *)c)->get();
@@ -177,7 +190,8 @@ int main(int argc, char **argv) {
     if (rc != 0 && err == "dump_only") { std::cout.flush(); fflush(nullptr); _exit(0); }   // -X: stop after the dump(s)
     if (rc != 0) { fprintf(stderr, "[E::main] %s\n", err.c_str()); dg_destroy(ctx); return 1; }
     dg_dp_timing tm;
-    if (p.opt.ploidy == 2 && dg_dp_get_timing(ctx, &tm) == DG_OK)
+    const bool have_tm = p.opt.ploidy == 2 && dg_dp_get_timing(ctx, &tm) == DG_OK;
+    if (have_tm)
         fprintf(stderr, "[dg::dp] delta %.3f ms, forward %.3f ms (%lld launches), traceback %.3f ms; %.3f G cells, %.3f G relaxations\n",
                 tm.delta_ms, tm.forward_ms, (long long)tm.n_forward_launches, tm.traceback_ms, p.sum.cells / 1e9, p.sum.relaxations / 1e9);
     if (!json.empty()) {
@@ -185,10 +199,11 @@ int main(int argc, char **argv) {
         if (f) {
             fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "
                        "\"spectrum\": %lld, \"n_levels\": %lld, \"n_vertices\": %lld, \"cells\": %llu, \"relaxations\": %llu, "
-                       "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"stages\": {",
+                       "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"dp_segments\": %d, \"dp_chunks\": %d, \"dp_forward_ms\": %.3f, \"dp_traceback_ms\": %.3f, \"stages\": {",
                     p.sum.dp_value, p.sum.s_het, p.sum.r1, p.sum.r2, p.sum.obj, (long long)p.sum.len1, (long long)p.sum.len2,
                     (long long)p.sum.spectrum, (long long)p.sum.n_levels, (long long)p.sum.n_vertices,
-                    (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll);
+                    (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll,
+                    have_tm ? tm.n_segments : 0, have_tm ? tm.n_chunks : 0, have_tm ? tm.forward_ms : 0.f, have_tm ? tm.traceback_ms : 0.f);
             for (size_t i = 0; i < p.sum.stage_s.size(); ++i)
                 fprintf(f, "%s\"%s\": %.6f", i ? ", " : "", p.sum.stage_s[i].first.c_str(), p.sum.stage_s[i].second);
             fprintf(f, "}}\n");

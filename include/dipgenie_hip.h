@@ -78,6 +78,8 @@ typedef struct dg_dp_timing {         /* HIP-event times of the last dg_dp_run, 
     uint64_t edge_pairs;              /* sum over levels of (in-edges into level)^2 */
     uint64_t colour_entries;          /* colour list entries read by the delta kernel */
     uint64_t state_bytes, bp_bytes, delta_bytes;   /* device allocations */
+    int32_t n_segments;               /* 1: the back-pointer lattice was resident; > 1: checkpoint + recompute in that many segments */
+    int32_t n_chunks;                 /* lattice chunks the levels were packed into */
 } dg_dp_timing;
 
 /* optional: reserve about `bytes` of back-pointer lattice (bytes <= 0: 60 % of the free HBM) in a background

@@ -53,3 +53,36 @@ def test_config5_panel_one_answer_in_every_execution_mode(c5_panel, gpu_ctx):
     finally:
         for k, v in {"digest": 0, "segment_cells": 0, "graph_batch": -1, "lattice_chunk_cells": 1 << 32, "fast": 1}.items():
             gpu_ctx.dp_set_option(k, v)
+
+
+def test_config5_5mbp_tier_naturally_segmented(built_hip, tmp_path_factory):
+    """BASELINE configs[4] at a tenth of its size: 5 Mbp backbone x 100 walks, R = 32 -- 7.1 x 10^11 cells, a 1.4 TB back-pointer
+    lattice that does NOT fit HBM, so checkpoint + recompute, delta windows and ~5.5 x 10^5 launches run as they do at full size
+    (nothing forced).  No reference answer exists (the reference would need a day), so size-independent properties: the lattice is
+    segmented; a different segmentation (smaller chunks) gives the same FASTA and value; the walked path re-scores to the DP value
+    in every run (dg_dp_run fails otherwise); the value is monotone in the recombination budget."""
+    d = tmp_path_factory.mktemp("c5_5m")
+    segs, links, walks, reads = synth.linear_panel(22, backbone_bp=5_000_000, n_haps=100)
+    synth.write_gfa(str(d / "c5.gfa"), segs, links, walks)
+    synth.write_fasta(str(d / "c5.fa"), reads)
+    del segs, links, walks, reads
+
+    def run(tag, R, options=None):
+        env = dict(os.environ)
+        if options:
+            env["DG_DP_OPTIONS"] = options
+        p = subprocess.run([built_hip, "-t16", "-p2", f"-R{R}", "-g", str(d / "c5.gfa"), "-r", str(d / "c5.fa"), "-o", str(d / f"{tag}.fa"), "-J", str(d / f"{tag}.json")],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        return open(d / f"{tag}.fa", "rb").read(), json.load(open(d / f"{tag}.json"))
+
+    fa, s32 = run("r32", 32)
+    assert s32["dp_segments"] > 1 and s32["dp_chunks"] > s32["dp_segments"], s32          # beyond HBM: checkpoint + recompute
+    assert s32["cells"] > 5e11 and s32["n_levels"] > 2e5 and s32["dp_value"] > 0 and s32["r1"] <= 32 and s32["r2"] <= 32
+    assert s32["len1"] > 4_500_000 and s32["len2"] > 4_500_000
+    fb, s32b = run("r32b", 32, "lattice_chunk_cells=%d" % (3 << 30))                       # 6 GB chunks: other chunk and segment boundaries
+    assert fb == fa and s32b["dp_value"] == s32["dp_value"] and (s32b["dp_chunks"], s32b["dp_segments"]) != (s32["dp_chunks"], s32["dp_segments"])
+    _, s28 = run("r28", 28)
+    _, s36 = run("r36", 36)
+    assert s28["dp_value"] <= s32["dp_value"] <= s36["dp_value"], (s28["dp_value"], s32["dp_value"], s36["dp_value"])
+    assert s28["cells"] * 33 == s32["cells"] * 29                                          # same graph, (R + 1) planes
