@@ -169,8 +169,6 @@ bool Pipeline::build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<An
             r.colours = ColourList{(int)colour}; r.nodeID = node;
         }
     }
-    color_homo_bv.assign(n_colours, 0);                              // approximator.cpp:1283-1290
-    for (int c = 0; c < n_colours; ++c) if (homo_bv[color_to_anchor[c]]) color_homo_bv[c] = 1;
     lap("anchor records");
 
     // ---- A4: per-vertex out-degree of everything but the overlap edges; start->super edges per haplotype in Anchor_hits order ----
@@ -329,6 +327,9 @@ bool Pipeline::build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<An
     std::thread kahn_thread;
     const int NTC = NT > 1 ? NT - 1 : 1;                             // threads of the colour work beside it
     if (NT > 1) kahn_thread = std::thread(kahn); else kahn();
+    wait_fit();                                                      // the grid fit has been running beside everything above: homo_bv from here on
+    color_homo_bv.assign(n_colours, 0);                              // approximator.cpp:1283-1290
+    for (int c = 0; c < n_colours; ++c) if (homo_bv[color_to_anchor[c]]) color_homo_bv[c] = 1;
     // ---- ... while the others build the colour CSR of G0 (:1240-1245: per node, the sorted-unique union of its records' lists).
     // Node ids of different haplotypes are disjoint: count (done in the sweep), scatter, then sort + unique the few nodes that
     // hold more than one colour.

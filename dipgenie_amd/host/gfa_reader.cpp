@@ -191,26 +191,44 @@ void finalize(Builder &b) {                                 // gfa-base.cpp:421-
     // gfa_fix_symm_add: a link and its complement pair up one-to-one; unmatched ones get a
     // complement added. With counts n_T of type T=(v,w,ov,ow) and n_T' of T'=(w^1,v^1,ow,ov) the
     // final multiplicity of both is max(n_T,n_T') (n_T if T is its own complement).
+    // (the distinct link types in sorted order with their counts: one sort instead of an ordered map of tuples)
     typedef std::tuple<uint32_t, uint32_t, int32_t, int32_t> Key;
-    std::map<Key, int64_t> cnt;
-    for (auto &a : b.arcs) cnt[Key(a.v, a.w, a.ov, a.ow)]++;
-    g.arcs.assign((size_t)2 * n, {});
-    for (auto &kv : cnt) {
-        uint32_t v = std::get<0>(kv.first), w = std::get<1>(kv.first);
-        int32_t ov = std::get<2>(kv.first), ow = std::get<3>(kv.first);
-        Key comp(w ^ 1, v ^ 1, ow, ov);
-        int64_t m = kv.second;
-        if (comp != kv.first) {
-            auto it = cnt.find(comp);
-            int64_t mc = it == cnt.end() ? 0 : it->second;
-            if (mc > m) m = mc;
-            if (it == cnt.end()) {   // complement absent: emit it here (it is not a key of cnt)
-                if (!g.seg_del[(w ^ 1) >> 1] && !g.seg_del[(v ^ 1) >> 1])
-                    for (int64_t c = 0; c < m; ++c) g.arcs[w ^ 1].push_back(v ^ 1);
+    std::vector<Key> keys;
+    keys.reserve(b.arcs.size());
+    for (auto &a : b.arcs) keys.emplace_back(a.v, a.w, a.ov, a.ow);
+    std::sort(keys.begin(), keys.end());
+    std::vector<std::pair<Key, int64_t>> cnt;
+    for (size_t q = 0; q < keys.size();) {
+        size_t q1 = q;
+        while (q1 < keys.size() && keys[q1] == keys[q]) ++q1;
+        cnt.emplace_back(keys[q], (int64_t)(q1 - q));
+        q = q1;
+    }
+    auto find = [&](const Key &k) -> const std::pair<Key, int64_t> * {
+        auto it = std::lower_bound(cnt.begin(), cnt.end(), k, [](const std::pair<Key, int64_t> &x, const Key &y) { return x.first < y; });
+        return it != cnt.end() && it->first == k ? &*it : nullptr;
+    };
+    std::vector<uint32_t> deg((size_t)2 * n, 0);
+    for (int pass = 0; pass < 2; ++pass) {                  // count, then fill: no per-vertex reallocation
+        if (pass == 1) { g.arcs.assign((size_t)2 * n, {}); for (size_t v = 0; v < deg.size(); ++v) if (deg[v]) g.arcs[v].reserve(deg[v]); }
+        for (auto &kv : cnt) {
+            uint32_t v = std::get<0>(kv.first), w = std::get<1>(kv.first);
+            int32_t ov = std::get<2>(kv.first), ow = std::get<3>(kv.first);
+            Key comp(w ^ 1, v ^ 1, ow, ov);
+            int64_t m = kv.second;
+            if (comp != kv.first) {
+                const auto *it = find(comp);
+                int64_t mc = it ? it->second : 0;
+                if (mc > m) m = mc;
+                if (!it) {   // complement absent: emit it here (it is not a key of cnt)
+                    if (!g.seg_del[(w ^ 1) >> 1] && !g.seg_del[(v ^ 1) >> 1]) {
+                        if (pass == 0) deg[w ^ 1] += (uint32_t)m; else for (int64_t c = 0; c < m; ++c) g.arcs[w ^ 1].push_back(v ^ 1);
+                    }
+                }
             }
+            if (g.seg_del[v >> 1] || g.seg_del[w >> 1]) continue;   // gfa_fix_arc_len / gfa_arc_rm
+            if (pass == 0) deg[v] += (uint32_t)m; else for (int64_t c = 0; c < m; ++c) g.arcs[v].push_back(w);
         }
-        if (g.seg_del[v >> 1] || g.seg_del[w >> 1]) continue;   // gfa_fix_arc_len / gfa_arc_rm
-        for (int64_t c = 0; c < m; ++c) g.arcs[v].push_back(w);
     }
 }
 

@@ -181,10 +181,17 @@ int main(int argc, char **argv) {
     p.be.anchor_begin = b_anchor_begin;
     p.be.anchor_add_haplotype = b_anchor_add;
     p.be.anchor_finish = b_anchor_finish;
-    if (getenv("DG_HOST_ANCHORS")) p.opt.host_anchors = true;   // A/B and parity runs: the host join / filter / sort
+    if (getenv("DG_HOST_ANCHORS")) p.opt.host_anchors = true;
+    p.opt.leak_at_exit = !getenv("DG_CLEAN_EXIT");   // A/B and parity runs: the host join / filter / sort
     p.be.last_error = b_last_error;
     std::string err;
+    if (dbg_tl) fprintf(stderr, "[dg::main] run() starts %.3f s after main\n", dg::now_s() - t0);
     int rc = p.run(err);
+    if (dbg_tl) {
+        fprintf(stderr, "[dg::main] run() returned %.3f s after main", dg::now_s() - t0);
+        for (auto &st : p.sum.stage_s) if (st.first == "total") fprintf(stderr, " (its own total: %.3f s)", st.second);
+        fputc('\n', stderr);
+    }
     dg_ctx *ctx = g_lazy.get();
     if (!ctx) { fprintf(stderr, "[E::main] %s\n", g_lazy.err.c_str()); return 2; }   // no gfx950 device: no CPU fallback
     if (rc != 0 && err == "dump_only") { std::cout.flush(); fflush(nullptr); _exit(0); }   // -X: stop after the dump(s)
@@ -216,6 +223,14 @@ int main(int argc, char **argv) {
         getrusage(RUSAGE_SELF, &ru);
         fprintf(stderr, "[dg::main] leaving %.3f s after exec; peak RSS %.2f GB, %ld minor page faults, user %.2f s, system %.2f s\n", since_exec_s(),
                 ru.ru_maxrss / 1048576.0, ru.ru_minflt, ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec);
+        if (FILE *f = fopen("/proc/self/smaps_rollup", "r")) {      // what the resident set is made of right now
+            char line[256];
+            while (fgets(line, sizeof line, f))
+                if (!strncmp(line, "Rss:", 4) || !strncmp(line, "AnonHugePages:", 14) || !strncmp(line, "Anonymous:", 10) || !strncmp(line, "Shared_Clean:", 13) ||
+                    !strncmp(line, "Private_Clean:", 14) || !strncmp(line, "Pss_File:", 9) || !strncmp(line, "Pss_Shmem:", 10))
+                    fprintf(stderr, "[dg::main] smaps_rollup %s", line);
+            fclose(f);
+        }
     }
     // Everything is written and closed.  Tearing down tens of GB of device chunks and host vectors one by one costs
     // ~0.4 s that the operating system does for free at exit; DG_CLEAN_EXIT=1 keeps the orderly path (leak checkers).

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <limits>
 #include <numeric>
@@ -223,18 +224,29 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
         if (be.anchor_begin(be.ctx, (int32_t)num_walks, (int32_t)n_vtx, top_order_map.data(), k, opt.w) != 0) {
             err = std::string("anchor_begin failed: ") + (be.last_error ? be.last_error() : "?"); return -1;
         }
-        std::string hap;
-        std::vector<int64_t> seg_start;
-        std::vector<int32_t> step_vtx;
-        for (uint32_t h = 0; h < num_walks; ++h) {
+        // the next haplotype's string and step arrays are assembled on a helper thread while the device works on this one
+        struct HapInput { std::string hap; std::vector<int64_t> seg_start; std::vector<int32_t> step_vtx; size_t tot = 0; };
+        auto assemble = [this](uint32_t h) {
+            HapInput in;
             const size_t ns = paths[h].size();
-            seg_start.assign(ns + 1, 0);
-            step_vtx.assign(paths[h].begin(), paths[h].end());
+            in.seg_start.assign(ns + 1, 0);
+            in.step_vtx.assign(paths[h].begin(), paths[h].end());
             size_t tot = 0;
-            for (size_t i = 0; i < ns; ++i) { seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
-            seg_start[ns] = (int64_t)tot;
-            hap.clear();
-            if (!(h < inj_hap.size() && inj_hap[h].set)) { hap.reserve(tot); for (size_t i = 0; i < ns; ++i) hap += node_seq[paths[h][i]]; }
+            for (size_t i = 0; i < ns; ++i) { in.seg_start[i] = (int64_t)tot; tot += node_seq[paths[h][i]].size(); }
+            in.seg_start[ns] = (int64_t)tot;
+            in.tot = tot;
+            if (!(h < inj_hap.size() && inj_hap[h].set)) { in.hap.reserve(tot); for (size_t i = 0; i < ns; ++i) in.hap += node_seq[paths[h][i]]; }
+            return in;
+        };
+        std::future<HapInput> next;
+        if (num_walks > 0) next = std::async(std::launch::async, assemble, 0u);
+        for (uint32_t h = 0; h < num_walks; ++h) {
+            HapInput cur = next.get();
+            if (h + 1 < num_walks) next = std::async(std::launch::async, assemble, h + 1);
+            const std::string &hap = cur.hap;
+            const std::vector<int64_t> &seg_start = cur.seg_start;
+            const std::vector<int32_t> &step_vtx = cur.step_vtx;
+            const size_t ns = paths[h].size(), tot = cur.tot;
             int64_t n = 0;
             const double ts0 = now_s();
             if (h < inj_hap.size() && inj_hap[h].set) {                // sketched by another rank
@@ -540,30 +552,49 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     int max_mult = 0;
     for (auto &kv : kmer_freq) { hist.push_back({(int)kv.first, (double)kv.second}); max_mult = std::max(max_mult, (int)kv.first); }
     if (!opt.quiet) std::cout << "Classifying kmers..." << std::endl;  // :784
-    sum.fit = kg_fit(hist, /*max_copy=*/10, max_mult, opt.threads);
+    // The grid fit (serial in the reference, :785) needs nothing but the histogram, and nothing before the colour split of the
+    // graph stage needs its result (homo_bv): it runs on a thread of its own beside the first phases of that stage
+    // (wait_fit() joins it and prints its two lines).
+    fit_t0 = t0;
+    auto job = [this, hist, max_mult, threads = std::max(1, opt.threads / 2)]() {
+        sum.fit = kg_fit(hist, /*max_copy=*/10, max_mult, threads);
+        const KGParams &P = sum.fit.P;
+        std::vector<int8_t> label(max_mult + 1, -1);
+        homo_bv.assign(count_sp_r, 0);                                 // :830-879
+        fit_n_hom = 0;
+        for (int32_t id = 0; id < count_sp_r; ++id) {
+            int m = fit_sp_count[id];
+            if (m == 0) continue;
+            if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
+            homo_bv[id] = (uint8_t)label[m];
+            fit_n_hom += label[m];
+        }
+    };
+    fit_sp_count.swap(sp_count);
+    fit_pending = true;
+    if (opt.threads > 1 && !getenv("DG_FIT_INLINE")) fit_thread = std::thread(job); else job();
+    return 0;
+}
+
+void Pipeline::wait_fit() {                                             // homo_bv is valid after this
+    if (!fit_pending) return;
+    if (fit_thread.joinable()) fit_thread.join();
+    fit_pending = false;
     const KGParams &P = sum.fit.P;
     if (!opt.quiet)
         fprintf(stderr, "[M::%s] Fitted model: best NLL=%.2f, u_v=%.2f (hom mean), sd_v=%.2f (hom SD), "
                 "var_w=%.2f, p_d=%.2f, zp_copy=%.2f, zp_copy_het=%.2f, err_shape=%.2f, max_copy=%d\n",
-                __func__, sum.fit.nll, P.u_v, P.sd_v, P.var_w, P.p_d, P.zp_copy, P.zp_copy_het, P.err_shape, P.max_copy);
-    std::vector<int8_t> label(max_mult + 1, -1);
-    homo_bv.assign(count_sp_r, 0);                                     // :830-879
-    int64_t n_hom = 0;
-    for (int32_t id = 0; id < count_sp_r; ++id) {
-        int m = sp_count[id];
-        if (m == 0) continue;
-        if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
-        homo_bv[id] = (uint8_t)label[m];
-        n_hom += label[m];
-    }
+                "compute_and_classify_anchors", sum.fit.nll, P.u_v, P.sd_v, P.var_w, P.p_d, P.zp_copy, P.zp_copy_het, P.err_shape, P.max_copy);
     if (!opt.quiet) {
         int64_t tot = std::max<int64_t>(1, count_sp_r);
-        fprintf(stderr, "[M::%s] Phasing done. Homozygous: %.2f%%, Heterozygous: %.2f%%, Total kmers: %lld\n", __func__,
-                100.f * float(n_hom) / tot, 100.f * float(count_sp_r - n_hom) / tot, (long long)count_sp_r);
+        fprintf(stderr, "[M::%s] Phasing done. Homozygous: %.2f%%, Heterozygous: %.2f%%, Total kmers: %lld\n", "compute_and_classify_anchors",
+                100.f * float(fit_n_hom) / tot, 100.f * float(count_sp_r - fit_n_hom) / tot, (long long)count_sp_r);
     }
-    stamp("fit+classify", t0);
-    return 0;
+    std::vector<int32_t>().swap(fit_sp_count);
+    stamp("fit+classify (joined)", fit_t0);
 }
+
+
 
 // ======================================================================================
 // ExpandedGraph  (ExpandedGraph.hpp:29-102, 269-409), flat CSR restatement
@@ -998,19 +1029,26 @@ std::vector<int> Pipeline::haploid_dp(const ExpandedGraph &g, int R, std::string
 // ======================================================================================
 int Pipeline::solve(std::string &err) {
     double t0 = now_s();
+    if (opt.ploidy != 2 || getenv("DG_GRAPH_LITERAL")) wait_fit();
     if (opt.ploidy == 2 && !getenv("DG_GRAPH_LITERAL")) {
         // the fused route (fast_graph.cpp) covers everything up to the levelized graph; it declines inputs it does not model
         // (empty walks, several sources, a vertex deeper than the sink ...), which then take the literal route below
-        ExpandedGraph gf;
-        std::vector<std::vector<AnchorRec>> anchorsByHapF;
+        // (heap objects: a process that is about to exit -- the CLI -- skips their teardown, ~0.07 s of munmap and 2 x 10^6 small
+        // destructors on MHC-24; Options::leak_at_exit)
+        ExpandedGraph *gf = new ExpandedGraph();
+        auto *anchorsByHapF = new std::vector<std::vector<AnchorRec>>();
         std::vector<uint8_t> color_homo_bv_f;
-        if (build_levelized_fast(gf, anchorsByHapF, color_homo_bv_f)) {
+        auto drop = [&]() { if (!opt.leak_at_exit) { delete gf; delete anchorsByHapF; } };
+        if (build_levelized_fast(*gf, *anchorsByHapF, color_homo_bv_f)) {
             stamp("levelized_graph_build", t0);
-            int rc = diploid(gf, color_homo_bv_f, anchorsByHapF, err);
+            int rc = diploid(*gf, color_homo_bv_f, *anchorsByHapF, err);
+            drop();
             if (rc != 0) return rc;
             if (!opt.quiet) std::cout << "Diploid sequences written to: " << opt.hap_file << std::endl;   // :1330
             return 0;
         }
+        delete gf; delete anchorsByHapF;
+        wait_fit();
         sum.n_colours = 0;
         t0 = now_s();
     }
@@ -1456,7 +1494,22 @@ int Pipeline::run(std::string &err) {                                  // main.c
     omp_set_num_threads(opt.threads);
 #endif
     t_run0 = now_s();
-    if (load_graph(err)) return -1;
+    // the reads file is parsed on a thread of its own beside the GFA (neither needs the other)
+    std::thread reads_thread;
+    std::string reads_err;
+    int reads_rc = 0;
+    double reads_dt = 0;
+    const bool want_reads = !spectrum_injected && (opt.ploidy == 1 || opt.ploidy == 2);
+    if (want_reads) reads_thread = std::thread([&] { const double t = now_s(); reads.clear(); reads_rc = read_sequences(opt.reads_file, reads, reads_err) ? 0 : -1; reads_dt = now_s() - t; });
+    const int grc = load_graph(err);
+    if (reads_thread.joinable()) reads_thread.join();
+    if (grc) return -1;
+    if (want_reads) {
+        if (reads_rc) { err = reads_err; return -1; }
+        sum.stage_s.emplace_back("read_ip_reads (beside the GFA)", reads_dt);
+        if (!opt.quiet) fprintf(stderr, "[dg::stage] %-28s %.3f s\n", "read_ip_reads (beside GFA)", reads_dt);
+        reads_loaded = true;
+    }
     return run_loaded(err);
 }
 
@@ -1479,9 +1532,10 @@ int Pipeline::run_loaded(std::string &err) {                           // main.c
         std::cout << "Current approximator support is only for ploidy = 1 or ploidy = 2" << std::endl;
         return 0;
     }
-    if (!spectrum_injected && load_reads(err)) return -1;
+    if (!spectrum_injected && !reads_loaded && load_reads(err)) return -1;
     if (compute_and_classify_anchors(err)) return -1;
     if (!opt.anchor_dump.empty()) {
+        wait_fit();
         if (!dump_anchors(opt.anchor_dump)) { err = "cannot write " + opt.anchor_dump; return -1; }
         if (opt.dump_only && opt.dump_prefix.empty()) { err = "dump_only"; return -1; }
     }

@@ -15,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <utility>
 #include <initializer_list>
 #include <utility>
@@ -70,6 +71,7 @@ struct Options {
     bool dump_only = false;   // (ours, tests) stop after the dump
     std::string anchor_dump;  // (ours, tests) if set, write Anchor_hits + homo_bv as text (format of oracle/ref_harness.cpp `anchors`)
     int haploid_mode = 0;        // (ours) haploid (vertex, r) tables: 0 = by graph shape, 1 = host gather loop, 2 = device (if the backend offers it)
+    bool leak_at_exit = false;   // (ours) the process exits right after run(): skip the teardown of the big graph objects
     bool host_anchors = false;   // (ours, tests) keep the anchor join / filter / sort on the host even if the backend offers it
 };
 
@@ -203,6 +205,17 @@ class Pipeline {
     bool build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<AnchorRec>> &anchorsByHap, std::vector<uint8_t> &color_homo_bv);
     void stamp(const char *name, double t0);
     double t_run0 = 0;
+    bool reads_loaded = false;
+    // fit + classify on its own thread (compute_and_classify_anchors starts it, wait_fit joins it)
+    std::thread fit_thread;
+    bool fit_pending = false;
+    double fit_t0 = 0;
+    int64_t fit_n_hom = 0;
+    std::vector<int32_t> fit_sp_count;
+    void wait_fit();
+  public:
+    ~Pipeline() { if (fit_thread.joinable()) fit_thread.join(); }
+  private:
 };
 
 double now_s();
