@@ -291,6 +291,9 @@ bool Pipeline::build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<An
         for (int hh = 0; hh < H; ++hh) { const int32_t ve = v2e[(size_t)v * H + hh]; if (ve >= 0) { dst0[o] = ve; w0[o] = 0; ++o; } }
     }
     { uvec<int32_t>().swap(v2e); }
+    // (nothing below needs the fill's inputs: at chr22 scale they are several GB each)
+    { std::vector<uvec<Ev>>().swap(events); std::vector<uvec<int32_t>>().swap(sup_edges); std::vector<uvec<OvEdge>>().swap(ov_edges); uvec<int32_t>().swap(n_ov); uvec<int32_t>().swap(deg0);
+      uvec<int32_t>().swap(sE); uvec<int32_t>().swap(eE); }
 #pragma omp parallel for num_threads(NT) schedule(static)
     for (int64_t e = 0; e < E0; ++e) {
 #pragma omp atomic
@@ -375,6 +378,7 @@ bool Pipeline::build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<An
     lap("colour CSR");
     if (kahn_thread.joinable()) kahn_thread.join();
     if (kahn_rc != 0) return false;
+    { uvec<int32_t>().swap(indeg); }
     const int32_t max_level = lvl[order[n0 - 1]];
     const int32_t L = max_level + 1;
     lap("kahn + levels");

@@ -15,6 +15,8 @@
 #error "define DGR_BACKEND_HIP (product) or DGR_BACKEND_ORACLE (test harness)"
 #endif
 
+static_assert(sizeof(dgr_options) == 56 && sizeof(dgr_summary) == 88, "layouts mirrored by dipgenie_amd/run_sharded.py");
+
 namespace {
 thread_local std::string g_err;
 int fail(const std::string &m) { g_err = m; return -1; }

@@ -27,7 +27,25 @@ def test_struct_layouts(built_hip):
     import ctypes as C
     from dipgenie_amd import capi
     assert C.sizeof(capi.DpGraph) == 80 and C.sizeof(capi.DpResult) == 72
-    assert C.sizeof(capi.DpTiming) == 64 and C.sizeof(capi.SketchTiming) == 24
+    assert C.sizeof(capi.DpTiming) == 72 and C.sizeof(capi.SketchTiming) == 24
+
+
+def test_run_library_exports_match_header(built_hip):
+    """libdipgenie_run.so (the host pipeline as a library, include/dipgenie_run.h): every declared entry point is exported, the
+    ctypes structs have the header's layout, and it links the HIP library -- never the oracle"""
+    import ctypes as C
+    import subprocess
+    from dipgenie_amd import run_sharded as rs
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dipgenie_run.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(dgr_[a-z_0-9]+)\s*\(", txt)))
+    assert len(syms) == 9
+    lib = rs.RunLib().lib
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert C.sizeof(rs.RunOptions) == 56 and C.sizeof(rs.RunSummary) == 88   # static_assert-ed in run_lib.cpp
+    out = subprocess.run(["ldd", rs.RUN_LIB], stdout=subprocess.PIPE).stdout.decode()
+    assert "libdipgenie_hip.so" in out and "oracle" not in out
+    assert "orc_" not in subprocess.run(["nm", "-D", rs.RUN_LIB], stdout=subprocess.PIPE).stdout.decode()
 
 
 def test_no_cpu_fallback(built_hip):
@@ -41,7 +59,7 @@ def test_no_cpu_fallback(built_hip):
 
 def test_product_does_not_link_oracle(built_hip):
     import subprocess
-    for f in (os.path.join(ROOT, "dipgenie_amd", "csrc", "libdipgenie_hip.so"), built_hip):
+    for f in (os.path.join(ROOT, "dipgenie_amd", "csrc", "libdipgenie_hip.so"), built_hip, os.path.join(ROOT, "dipgenie_amd", "host", "libdipgenie_run.so")):
         out = subprocess.run(["ldd", f], stdout=subprocess.PIPE).stdout.decode()
         assert "oracle" not in out
         sym = subprocess.run(["nm", "-D", f], stdout=subprocess.PIPE).stdout.decode()

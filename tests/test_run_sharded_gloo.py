@@ -58,7 +58,7 @@ def _worker(rank, world, port, a, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("bub_a", 1), ("bub_a", 2), ("bub_e", 3), ("bub_h", 2), ("toy1_p2", 3), ("c5s", 2)])
+@pytest.mark.parametrize("name,world", [("bub_a", 1), ("bub_a", 2), ("bub_e", 3), ("bub_h", 2), ("toy1_p2", 3)])
 def test_sharded_run_gives_the_reference_fasta(name, world, built_cpu, tmp_path):
     assert os.path.exists(RUN_LIB), "tests/harness/libdg_run_oracle.so missing (make -C tests/harness)"
     case = CASES[name]
