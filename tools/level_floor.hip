@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -105,6 +106,56 @@ __global__ __launch_bounds__(256) void k_chain(int G, int level0, const uint32_t
     __hip_atomic_store(&nxt[t & mask], (x + 4096u) & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&done[lvl], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Chained levels with PER-PRODUCER flags (round 3): the consumer wave polls only the flag of the ONE workgroup of the previous level
+// whose 1 KB region it gathers from -- no counter shared by a whole level.  Producer: `sc1` (write-through) stores, every wave's
+// s_waitcnt vmcnt(0), workgroup barrier, one `sc1` flag store on a 128-byte line of its own; consumer: `sc1` poll, then `sc1` gathers
+// (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads in place of the acquire", first row).  The state lives in a ring of RING
+// buffers so that a line is rewritten only RING levels later (ping-pong would leave a two-level-old copy in the reader XCD's L2, which
+// `sc1` loads are served from).  Spins are bounded (abort flag); workgroups of level q have higher block ids than those of level
+// q - 1, so what a spinner waits for is resident or ahead of it in the dispatch order.
+constexpr int RING = 8;
+struct RingBufs { uint32_t *b[RING]; };
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_chain_rows(int G, int level0, const uint32_t *__restrict__ rec, RingBufs st, uint32_t mask, uint32_t *flags /* [RING][G][32] */, Ctl *ctl, int cold_stride) {
+    const int q = (int)blockIdx.x / G, w = (int)blockIdx.x % G, lvl = level0 + q;
+    const uint32_t t = (uint32_t)w * 256u + threadIdx.x;
+    const uint32_t *cur = st.b[lvl % RING];
+    uint32_t *nxt = st.b[(lvl + 1) % RING];
+    uint32_t x = rec[(size_t)(lvl & 4095) * cold_stride + t];          // round 1: independent of the previous level
+#pragma unroll
+    for (int r = 1; r < ROUNDS; ++r) {
+        const uint32_t idx = (x + (uint32_t)r * 64u) & mask;
+        if (q > 0) {                                                    // (level0 follows a kernel boundary: everything visible)
+            const uint32_t prod = __builtin_amdgcn_readfirstlane(idx >> 8);   // the producer workgroup of this wave's 64 words
+            const uint32_t *f = flags + ((size_t)(lvl % RING) * G + prod) * 32;
+            uint32_t spin = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)lvl) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spin > (1u << 16) || __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        x = __hip_atomic_load(&cur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(&nxt[t & mask], (x + 4096u) & mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + ((size_t)((lvl + 1) % RING) * G + w) * 32, (uint32_t)(lvl + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same levels as ONE launch each over the same ring (reference for time and for the final state)
+template <int ROUNDS>
+__global__ __launch_bounds__(256) void k_ring_level(int lvl, const uint32_t *__restrict__ rec, RingBufs st, uint32_t mask, int cold_stride) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t *cur = st.b[lvl % RING];
+    uint32_t *nxt = st.b[(lvl + 1) % RING];
+    uint32_t x = rec[(size_t)(lvl & 4095) * cold_stride + t];
+#pragma unroll
+    for (int r = 1; r < ROUNDS; ++r) x = cur[(x + (uint32_t)r * 64u) & mask];
+    nxt[t & mask] = (x + 4096u) & mask;
 }
 
 int main(int argc, char **argv) {
@@ -268,6 +319,50 @@ int main(int argc, char **argv) {
             }
         }
         CK(hipFree(done));
+    }
+    if (G * 256 == (int)words) {   // chained levels with per-producer flags (k_chain_rows); needs one workgroup per 256 state words
+        RingBufs rb;
+        for (int q = 0; q < RING; ++q) CK(hipMalloc(&rb.b[q], words * 4));
+        uint32_t *flags; CK(hipMalloc(&flags, (size_t)RING * G * 32 * 4));
+        std::vector<uint32_t> init(words), ref(words), got(words);
+        for (uint32_t i = 0; i < words; ++i) init[i] = i;
+        auto reset = [&]() -> int { for (int q = 0; q < RING; ++q) CK(hipMemcpy(rb.b[q], init.data(), words * 4, hipMemcpyHostToDevice)); CK(hipMemset(flags, 0xFF, (size_t)RING * G * 32 * 4)); return 0; };
+        const int NL = (std::min(N, 4096) / 64) * 64;
+        for (int rounds : {2, 5}) {
+            if (reset()) return 1;
+            CK(hipEventRecord(e0, s));
+            for (int l = 0; l < NL; ++l) {
+                if (rounds == 2) hipLaunchKernelGGL((k_ring_level<2>), dim3(G), dim3(256), 0, s, l, rec, rb, mask, G * 256);
+                else hipLaunchKernelGGL((k_ring_level<5>), dim3(G), dim3(256), 0, s, l, rec, rb, mask, G * 256);
+            }
+            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(ref.data(), rb.b[NL % RING], words * 4, hipMemcpyDeviceToHost));
+            printf("ring%d       %7.3f us/level   (%d levels, one launch per level, ring of %d state buffers)\n", rounds, 1e3 * ms / NL, NL, RING);
+            for (int M : {4, 16, 64}) {
+                float best = 1e30f; uint32_t aborted = 0; size_t wrong = 0;
+                for (int rep = 0; rep < 2; ++rep) {
+                    if (reset()) return 1;
+                    CK(hipMemsetAsync(ctl, 0, sizeof(Ctl), s));
+                    CK(hipEventRecord(e0, s));
+                    for (int l0 = 0; l0 < NL; l0 += M) {
+                        if (rounds == 2) hipLaunchKernelGGL((k_chain_rows<2>), dim3(G * M), dim3(256), 0, s, G, l0, rec, rb, mask, flags, ctl, G * 256);
+                        else hipLaunchKernelGGL((k_chain_rows<5>), dim3(G * M), dim3(256), 0, s, G, l0, rec, rb, mask, flags, ctl, G * 256);
+                    }
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    Ctl h; CK(hipMemcpy(&h, ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+                    aborted |= h.abort;
+                    CK(hipMemcpy(got.data(), rb.b[NL % RING], words * 4, hipMemcpyDeviceToHost));
+                    wrong = 0; for (uint32_t i = 0; i < words; ++i) wrong += got[i] != ref[i];
+                    if (ms < best) best = ms;
+                }
+                printf("rowflag%d x%-3d %6.3f us/level   (%d levels, %d workgroups per level, %d levels per dispatch; final state: %zu of %u words differ)%s\n", rounds, M, 1e3 * best / NL, NL, G, M,
+                       wrong, words, aborted ? "  ABORTED (spin timeout)" : "");
+            }
+        }
+        CK(hipFree(flags));
+        for (int q = 0; q < RING; ++q) CK(hipFree(rb.b[q]));
     }
     if (argc > 3) return 0;                                         // a third argument: skip the persistent variants
     // persistent grid + device-wide barrier per level (all workgroups resident: at most 2 per CU)
