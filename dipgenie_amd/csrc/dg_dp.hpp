@@ -42,6 +42,7 @@ constexpr int ROWX_MAX = 64;                            // widest row in-edge ma
 constexpr int DELTA_PER_BLOCK = 256 * 16;
 constexpr int DELTA_PAD = 8;                            // delta[0..8) stays zero: the colourless transitions' slot
 constexpr int32_t CHAIN_CORRUPT = INT32_MIN;            // ChainState::value after a hop left its level
+constexpr int RING = 16;                                // rolling value state: level l lives in slot l % RING (chained dispatches keep up to RING - 1 levels in flight)
 
 struct LevelDesc {                                      // transition (l-1) -> l, indexed by l; passed BY VALUE to the sweep
     int32_t a0, k;                                      // source level: first vertex id, width
@@ -75,7 +76,8 @@ struct SweepArgs {                                      // generic sweep kernel
     const uint32_t *in_off, *in_edge, *grp_begin;
     const int32_t *in_dst, *dead_cols;
     const uint16_t *delta, *delta_zero;                 // delta: biased so that delta[d.delta_off] is valid for the resident window
-    int32_t *buf0, *buf1;
+    char *ring;                                         // state slots, each slot_bytes long, data starts pad_bytes in
+    size_t slot_bytes, pad_bytes;
     uint16_t *bp;
     unsigned long long *digest;
     int RP;
@@ -88,11 +90,12 @@ struct FastArgs {                                       // fast sweep kernel
     const uint32_t *in_edge, *rowx;
     const int32_t *dead_cols;
     const uint16_t *delta, *delta_zero;
-    int32_t *base0, *base1;                             // padded allocation starts of the two state buffers
+    char *ring;                                         // padded allocation start of state slot 0; slot s starts at ring + s * slot_bytes
     uint16_t *bp;                                       // fast-form levels always store narrow back-pointers
     unsigned long long *digest;
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
-    uint32_t buf_bytes;                                 // size of one padded state buffer
+    uint32_t buf_bytes;                                 // size of one padded state buffer (what a buffer resource covers)
+    uint32_t slot_bytes;                                // distance between two state slots
     int *progress;                                      // PfCtl::level: the level whose launch is running (L2 prefetcher)
 #ifdef DG_SWEEP_PROBE
     unsigned long long *probe;                          // measurement build: 8 words per level
@@ -172,7 +175,7 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t n_grp = 0, n_dead = 0, n_heavy_rows = 0, n_slot_records = 0, n_rowx_words = 0, n_dtrans = 0, n_edges = 0;   // logical table sizes (dg_dp_get_table_digest)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
-    DevBuf d_delta, d_bp, d_val[2], d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
+    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
 #ifdef DG_SWEEP_PROBE
     DevBuf d_probe;
 #endif

@@ -26,6 +26,7 @@ void dp_state_free(DpState *s) {
     sweep_prefetch_free(*s);
     delta_overlap_free(*s);
     { std::unique_lock<std::mutex> lk(s->pool.mu); s->pool.target = 0; }
+    s->pool.cv.notify_all();
     if (s->pool.th.joinable()) s->pool.th.join();
     const double tf0 = wall_s();
     for (void *q : s->pool.chunks) (void)hipFree(q);
@@ -53,7 +54,8 @@ void pool_request(DpState &S, int device, size_t target) {
             size_t bytes;
             {
                 std::unique_lock<std::mutex> lk2(Sp->pool.mu);
-                Sp->pool.cv.wait(lk2, [&] { return !Sp->pool.paused; });
+                // (a lowered target must get through a pause: pool_trim joins this thread while dg_dp_load_graph holds the pause)
+                Sp->pool.cv.wait(lk2, [&] { return !Sp->pool.paused || Sp->pool.chunks.size() >= Sp->pool.target; });
                 if (Sp->pool.chunks.size() >= Sp->pool.target) { Sp->pool.running = false; Sp->pool.cv.notify_all(); return; }
                 bytes = Sp->pool.chunk_units * 2;
             }
@@ -73,8 +75,9 @@ PoolPause::PoolPause(DpState &s) : S(s) { std::unique_lock<std::mutex> lk(S.pool
 PoolPause::~PoolPause() { { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.paused = false; } S.pool.cv.notify_all(); }
 // free chunks beyond `keep` (and stop asking for more than that)
 void pool_trim(DpState &S, size_t keep) {
-    { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.target = std::min(S.pool.target, keep); }
-    if (S.pool.th.joinable()) S.pool.th.join();               // it stops at the next chunk boundary
+    { std::unique_lock<std::mutex> lk(S.pool.mu); S.pool.target = std::min(std::min(S.pool.target, keep), S.pool.chunks.size()); }
+    S.pool.cv.notify_all();
+    if (S.pool.th.joinable()) S.pool.th.join();               // it stops at the next chunk boundary (a paused one: at once)
     std::unique_lock<std::mutex> lk(S.pool.mu);
     while (S.pool.chunks.size() > keep) { (void)hipFree(S.pool.chunks.back()); S.pool.chunks.pop_back(); }
     S.pool.running = false;
@@ -102,7 +105,7 @@ struct Run {
 
     Run(dg_ctx *c_, DpState &S_) : c(c_), S(S_), s(c_->stream) { sweep_prepare(S, X); }
     int n_win() const { return (int)S.dwin_t.size() - 1; }
-    int32_t *state_ptr(int level) const { return S.d_val[level & 1].as<int32_t>() + S.pad_front; }
+    int32_t *state_ptr(int level) const { return (int32_t *)(S.d_ring.as<char>() + (size_t)(level & (RING - 1)) * S.state_alloc_bytes) + S.pad_front; }
     size_t level_cells(int level) const {               // state size of a level (level 0: the source, k = 1)
         const int64_t k = level == 0 ? 1 : S.descs[level].k2;
         return (size_t)(k * k * S.RP);

@@ -46,8 +46,8 @@ template <int RC, bool DIGEST>
 __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, int wave_id, int n_waves) {
     const LevelDesc d = A.descs[lvl];
     const int RP = A.RP;
-    const int32_t *__restrict__ cur = ((lvl - 1) & 1) ? A.buf1 : A.buf0;
-    int32_t *__restrict__ nxt = (lvl & 1) ? A.buf1 : A.buf0;
+    const int32_t *__restrict__ cur = (const int32_t *)(A.ring + (size_t)((lvl - 1) & (RING - 1)) * A.slot_bytes + A.pad_bytes);
+    int32_t *__restrict__ nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
     const int lane = threadIdx.x & 63;
     const int nchunk = (RP + RC - 1) / RC;
     const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(DG_PLAIN_WG) void dp_sweep_fast_kernel(const uint4 
     const int g = (int)blockIdx.x * DG_PLAIN_GW + (wv % DG_PLAIN_GW);    // always launched with DG_PLAIN_WG threads (reading blockDim would be a kernel-argument load)
     const int r0 = ((int)blockIdx.y * DG_PLAIN_CH + wv / DG_PLAIN_GW) * RC;
     if (g >= nblocks || r0 >= (rp_k & 0x1FFF)) return;                  // wave-uniform; no block barrier below
-    int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    int32_t *nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
     sweep_task<RC, DIGEST, GENERAL, 0>(H, A, d, state_rsrc(cur, buf_bytes), nxt, (int)blockIdx.z, g, r0, lvl);
 }
 
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
                                                             FastArgs A, LevelDesc d, int lvl, const uint16_t *dm, int dT, const int32_t *__restrict__ heavy_rows) {
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, A.pad_bytes, dT, A.buf_bytes};
     publish_level(A.progress, lvl);
-    int32_t *nxt = ((lvl & 1) ? A.base1 : A.base0) + A.pad_bytes / 4;
+    int32_t *nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
     const int zc = 4 * n_heavy;
     if ((int)blockIdx.z < zc) {
@@ -593,27 +593,27 @@ __global__ __launch_bounds__(64) void dp_l2_prefetch_kernel(const LevelDesc *__r
 // ---------------------------------------------------------------------------------------------
 void sweep_prepare(const DpState &S, SweepLaunch &X) {
     X.rc_sel = S.RP <= 8 ? 8 : (S.RP <= 19 ? 19 : 33);
-    X.small_state = S.state_alloc_bytes < ((size_t)1 << 31);            // 32-bit buffer offsets
+    X.small_state = S.state_alloc_bytes < ((size_t)1 << 31);            // 32-bit buffer offsets inside a slot
     SweepArgs &A = X.A;
     A.descs = S.d_descs.as<LevelDesc>(); A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
     A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
     A.delta = A.delta_zero = S.d_delta.as<uint16_t>();
-    A.buf0 = S.d_val[0].as<int32_t>() + S.pad_front; A.buf1 = S.d_val[1].as<int32_t>() + S.pad_front;
+    A.ring = S.d_ring.as<char>(); A.slot_bytes = S.state_alloc_bytes; A.pad_bytes = 4 * (size_t)S.pad_front;
     A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
     FastArgs &F = X.F;
     F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.rowx = S.d_rowx.as<uint32_t>(); F.dead_cols = A.dead_cols;
     F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
-    F.base0 = S.d_val[0].as<int32_t>(); F.base1 = S.d_val[1].as<int32_t>();
+    F.ring = S.d_ring.as<char>(); F.slot_bytes = (uint32_t)S.state_alloc_bytes;
 #ifdef DG_SWEEP_PROBE
     F.probe = S.d_probe.as<unsigned long long>();
 #endif
     F.progress = A.progress = &S.d_pfctl.as<PfCtl>()->level;
     F.pad_bytes = (int)(4 * S.pad_front);
-    F.buf_bytes = (uint32_t)std::min<size_t>(std::min(S.d_val[0].bytes, S.d_val[1].bytes), 0x7FFFFFFFu);
+    F.buf_bytes = (uint32_t)std::min<size_t>(S.state_alloc_bytes, 0x7FFFFFFFu);
 }
 
 void sweep_init_state(const DpState &S, hipStream_t s) {
-    hipLaunchKernelGGL(dp_init_kernel, dim3((unsigned)((S.RP + 255) / 256)), dim3(256), 0, s, S.d_val[0].as<int32_t>() + S.pad_front, S.RP);
+    hipLaunchKernelGGL(dp_init_kernel, dim3((unsigned)((S.RP + 255) / 256)), dim3(256), 0, s, S.d_ring.as<int32_t>() + S.pad_front, S.RP);
 }
 
 // A lone wave retires ~1 instruction per 4-8 cycles, so an RC-fold unrolled task is the level's critical path: while
@@ -664,7 +664,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const uint4 *rowrec_l = F.rowrec + d.b0;
         const uint2 *slots_l = F.slots + d.slot_first;
         const uint32_t *rowx_l = F.rowx + d.rowx_off;
-        const int32_t *cur = ((l - 1) & 1) ? F.base1 : F.base0;
+        const int32_t *cur = (const int32_t *)(F.ring + (size_t)((l - 1) & (RING - 1)) * F.slot_bytes);
         const int dT = d.delta_off >= 0 ? d.T : 0;
         const uint16_t *dm = dT ? F.delta + d.delta_off - (int64_t)d.in_base * dT : F.delta_zero;   // (F.delta is biased by the resident delta window)
         const int rp_k = S.RP | (d.k << 13);

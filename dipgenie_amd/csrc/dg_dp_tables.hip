@@ -416,7 +416,7 @@ int plan_lattice(dg_ctx *c, DpState &S, size_t st_bytes, size_t dl_bytes, size_t
     DG_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t pool_bytes;
     { std::unique_lock<std::mutex> lk(S.pool.mu); pool_bytes = S.pool.chunks.size() * S.pool.chunk_units * 2; }
-    const size_t have = free_b + pool_bytes + S.d_bp.bytes + S.d_delta.bytes + S.d_val[0].bytes + S.d_val[1].bytes + S.d_ckpt.bytes;
+    const size_t have = free_b + pool_bytes + S.d_bp.bytes + S.d_delta.bytes + S.d_ring.bytes + S.d_ckpt.bytes;
     const size_t fixed = st_bytes + dl_bytes + table_bytes + ((size_t)2 << 30);     // state, delta, tables, slack
     if (fixed > have) {
         set_error("graph needs %.1f GB of HBM for state/delta/tables but only %.1f GB is free", fixed / 1e9, have / 1e9);
@@ -563,7 +563,7 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.n_edges = g->out_off[nV];
     plan_delta_windows(S, dtrans, dblk_first);
     const size_t n_edges = (size_t)g->out_off[nV];
-    const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_buf_entries * 2;
+    const size_t st_bytes = (size_t)S.max_level_cells * 4 * RING, dl_bytes = (size_t)S.delta_buf_entries * 2;
     size_t bp_bytes = 0, ck_bytes = 0;
     // (the tables are allocated already; what follows: edge flags + self scores, digests, the path)
     if (int rc = plan_lattice(c, S, st_bytes, dl_bytes, 3 * n_edges + 16 * (size_t)L + (1 << 20), bp_bytes, ck_bytes, dbg)) return rc;
@@ -580,16 +580,14 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     DG_HIP(hipMemsetAsync(S.d_chain.p, 0, 128, s)); S.chain_seq = 0;
     S.pad_front = 2 * (int64_t)max_k;
     const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)max_k);
-    if (int rc = S.d_val[0].ensure(st_bytes / 2 + pad_bytes)) return rc;
-    if (int rc = S.d_val[1].ensure(st_bytes / 2 + pad_bytes)) return rc;
-    DG_HIP(hipMemsetAsync(S.d_val[0].p, 0, S.d_val[0].bytes, s));
-    DG_HIP(hipMemsetAsync(S.d_val[1].p, 0, S.d_val[1].bytes, s));
+    S.state_alloc_bytes = (((size_t)S.max_level_cells * 4 + pad_bytes) + 255) & ~(size_t)255;   // one slot
+    if (int rc = S.d_ring.ensure(S.state_alloc_bytes * RING)) return rc;
+    DG_HIP(hipMemsetAsync(S.d_ring.p, 0, S.state_alloc_bytes * RING, s));
     if (int rc = S.d_digest.ensure(8 * (size_t)L)) return rc;
 #ifdef DG_SWEEP_PROBE
     if (int rc = S.d_probe.ensure(64 * (size_t)L)) return rc;
 #endif
     if (int rc = S.d_trace.ensure(sizeof(TraceOut))) return rc;
-    S.state_alloc_bytes = st_bytes / 2 + pad_bytes;
     S.cap = 2 * (R + 8);                               // edge records of both paths
     if (int rc = S.d_edges.ensure(4 * 4 * (size_t)S.cap)) return rc;
     if (int rc = S.d_path.ensure(8 * (size_t)L)) return rc;
