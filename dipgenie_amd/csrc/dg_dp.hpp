@@ -67,6 +67,17 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t dmax;                                       // largest in-degree among the level's vertices (host: choice of RC)
 };
 
+// Chained dispatch (dg_dp_sweep.hip: dp_sweep_chain_kernel): per destination level, what a per-level launch passes as kernel arguments
+struct ChainLevel {
+    const uint4 *rowrec_l; const uint2 *slots_l; const uint32_t *rowx_l; const uint16_t *dm;
+    int32_t rowx_stride, nblocks, n_heavy, rp_k;        // rp_k = RP | k << 13
+    int32_t dT, gx, gy, zc;                             // grid of the level (x: slot-block quads, y: r chunks); zc = 4 * n_heavy where the rows with many in-edges get cooperative workgroups, else 0
+    int32_t a0, bp_nt, n_wg, pad_;                      // first vertex of the source level; stream the back-pointers non-temporally; workgroups of the level
+    uint32_t expect_src, expect_own;                    // a complete row's counter: in the source level / in this level (5 per (x, y) pair)
+    unsigned long long heavy_lo, heavy_hi;
+};
+struct ChainDispatch { int32_t l0, M; uint32_t pre[RING]; int32_t dbg; unsigned long long *probe; };   // levels [l0, l0 + M), M < RING; pre[q] = first workgroup of level l0 + q
+
 struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt, path_score; };   // path_score: sum of the score deltas along the walked path (must equal value)
 struct ChainState { int32_t i, j, r, value; };
 struct ColourCsr { const int64_t *hom_off, *het_off; const int32_t *hom_col, *het_col; };
@@ -85,6 +96,8 @@ struct SweepArgs {                                      // generic sweep kernel
 };
 
 struct FastArgs {                                       // fast sweep kernel
+    const LevelDesc *descs;                             // (chained dispatches fetch their levels' descriptors themselves)
+    const int32_t *heavy_rows;
     const uint4 *rowrec;
     const uint2 *slots;
     const uint32_t *in_edge, *rowx;
@@ -126,6 +139,17 @@ struct DpState {
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's host table construction
     int64_t test_poison_level = 0, test_poison_byte = 0xFF;   // test_poison_*: overwrite one level of the lattice between sweep and walk (tests of the corrupt-lattice path)
+    int64_t use_chain = 0;                              // chain: 1 = consecutive levels in one dispatch with row-completion counters instead of kernel boundaries.
+                                                        // Correct (every digest equal) and measured: 13-27 us per level on MHC-24 against 4.1 us for one launch per level --
+                                                        // the row counters are hot lines (10-30 adds + the polls of 30-90 consumer workgroups each); off by default, DESIGN.md s3.3
+    int64_t chain_rc = 2;                               // chain_rc: recombination counts per task in chained dispatches (1..4)
+    int64_t chain_dbg = 0;                              // (experiments: 1 = no wait, 2 = no counter add, 4 = no record touch)
+    int64_t chain_max = RING - 1;                       // chain_max: levels per chained dispatch (2 .. RING - 1)
+    bool chain_failed = false;                          // a chained dispatch timed out once: per-level launches from then on
+    std::vector<ChainLevel> chain_host;                 // built by the first run after a load / option change
+    int64_t chain_built_rc = 0;
+    const void *chain_built_delta = nullptr;
+    int64_t levels_chained = 0;                         // levels of the last run that went out in chained dispatches
     int64_t host_tables = 0;                            // host_tables: 1 = build the tables on the host and upload them (dg_dp_tables.hip; parity twin of dg_dp_build.hip)
     int64_t bp_nt_min_cells = 262144;                   // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
@@ -175,7 +199,7 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t n_grp = 0, n_dead = 0, n_heavy_rows = 0, n_slot_records = 0, n_rowx_words = 0, n_dtrans = 0, n_edges = 0;   // logical table sizes (dg_dp_get_table_digest)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
-    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
+    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl, d_chainlv, d_rowdone, d_chainprobe;
 #ifdef DG_SWEEP_PROBE
     DevBuf d_probe;
 #endif
@@ -241,6 +265,9 @@ struct SweepLaunch {                     // per-run launch context
 void sweep_prepare(const DpState &S, SweepLaunch &X);
 void sweep_init_state(const DpState &S, hipStream_t s);                  // level 0: every r starts at 0 (:534-535)
 void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s);
+int sweep_chain_prepare(DpState &S, SweepLaunch &X, hipStream_t s);            // per-level parameters of chained dispatches (device array), counters
+bool sweep_chain_ok(const DpState &S, const SweepLaunch &X, int l);             // level l may be part of a chained dispatch
+void sweep_launch_chain(DpState &S, SweepLaunch &X, int l0, int M, hipStream_t s);   // levels [l0, l0 + M) in one dispatch
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s);
 int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s);
 void sweep_prefetch_end(DpState &S, int le, hipStream_t s);

@@ -106,6 +106,8 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
  *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
+ *   chain 0|1, chain_rc n, chain_max n   consecutive levels in ONE dispatch with row-completion counters in place of kernel boundaries
+ *                         (default 0 = one launch per level: the chained form is correct but 3-6x slower); recombination counts per task (1..4, default 2); levels per dispatch (2..15)
  *   side_stream -1|0|1    L2 prefetcher + score deltas beside the sweep: -1 (default) while this is the only DP state on its device, 0 never, 1 always
  *   test_poison_level l, test_poison_byte b   tests: fill level l of the back-pointer lattice with byte b between sweep and walk (dg_dp_run must answer DG_ERR_STATE)
  *   host_tables 0|1       0 (default): the sweep's tables are built by device kernels from the uploaded graph; 1: on the host, then uploaded (parity twin; next load)

@@ -161,12 +161,13 @@ def test_dp_device_tables_equal_host_tables(gpu_ctx):
         gpu_ctx.dp_set_option("host_tables", 0)
 
 
-@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch", "host_tables"])
+@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch", "host_tables", "chained", "chained_rc1", "chained_rc4"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
     """the generic fallback sweep, the fixed-RC launch, cooperative rows off / forced, the path without row in-edge
     matrices and the general chain walk (in place of the lean one) must all give the oracle's answer"""
     opts = {"generic": {"fast": 0}, "no_adaptive": {"adaptive_rc": 0}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}, "no_rowx": {"rowx": 0},
-            "general_chain": {"lean_chain": 0}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}, "host_tables": {"host_tables": 1}}[mode]
+            "general_chain": {"lean_chain": 0}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}, "host_tables": {"host_tables": 1},
+            "chained": {"chain": 1}, "chained_rc1": {"chain": 1, "chain_rc": 1, "chain_max": 3}, "chained_rc4": {"chain": 1, "chain_rc": 4, "chain_max": 7}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -181,7 +182,7 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
                          (7, dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8)), (8, dict(max_width=70, n_levels=12, R=4, extra_edges=3.0))]:
             _dp_both(gpu_ctx, graphgen.random_levelized(7100 + seed, **kw))
     finally:
-        for k, v in {"fast": 1, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128, "host_tables": 0}.items():
+        for k, v in {"fast": 1, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128, "host_tables": 0, "chain": 0, "chain_rc": 2, "chain_max": 15}.items():
             gpu_ctx.dp_set_option(k, v)
 
 
