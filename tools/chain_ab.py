@@ -9,7 +9,7 @@ import numpy as np
 from dipgenie_amd import capi
 
 g = capi.DpGraphArrays.load(sys.argv[1])
-sets = ["chain=0"] + (sys.argv[2:] or ["chain=1"])
+sets = sys.argv[2:] or ["chain=0", "chain=1"]                  # the first set is the reference
 ctx = capi.Context(0)
 ctx.dp_load_graph(g)
 ref = None
