@@ -89,6 +89,7 @@ struct SweepArgs {                                      // generic sweep kernel
     const uint16_t *delta, *delta_zero;                 // delta: biased so that delta[d.delta_off] is valid for the resident window
     char *ring;                                         // state slots, each slot_bytes long, data starts pad_bytes in
     size_t slot_bytes, pad_bytes;
+    int ring_mask;
     uint16_t *bp;
     unsigned long long *digest;
     int RP;
@@ -96,8 +97,6 @@ struct SweepArgs {                                      // generic sweep kernel
 };
 
 struct FastArgs {                                       // fast sweep kernel
-    const LevelDesc *descs;                             // (chained dispatches fetch their levels' descriptors themselves)
-    const int32_t *heavy_rows;
     const uint4 *rowrec;
     const uint2 *slots;
     const uint32_t *in_edge, *rowx;
@@ -109,6 +108,7 @@ struct FastArgs {                                       // fast sweep kernel
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
     uint32_t buf_bytes;                                 // size of one padded state buffer (what a buffer resource covers)
     uint32_t slot_bytes;                                // distance between two state slots
+    int ring_mask;                                      // level l lives in slot l & ring_mask
     int *progress;                                      // PfCtl::level: the level whose launch is running (L2 prefetcher)
 #ifdef DG_SWEEP_PROBE
     unsigned long long *probe;                          // measurement build: 8 words per level
@@ -145,6 +145,13 @@ struct DpState {
     int64_t chain_rc = 2;                               // chain_rc: recombination counts per task in chained dispatches (1..4)
     int64_t chain_dbg = 0;                              // (experiments: 1 = no wait, 2 = no counter add, 4 = no record touch)
     int64_t chain_max = RING - 1;                       // chain_max: levels per chained dispatch (2 .. RING - 1)
+    // two slots (ping-pong: the pair stays in the L2s and the Infinity Cache -- the MHC-24 sweep is 2 % slower over all 16) unless chained
+    // dispatches, which keep up to RING - 1 levels in flight, are switched on
+#ifdef DG_CHAIN
+    int ring_mask() const { return use_chain ? RING - 1 : 1; }
+#else
+    int ring_mask() const { return 1; }
+#endif
     bool chain_failed = false;                          // a chained dispatch timed out once: per-level launches from then on
     std::vector<ChainLevel> chain_host;                 // built by the first run after a load / option change
     int64_t chain_built_rc = 0;

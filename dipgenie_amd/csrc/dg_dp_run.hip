@@ -106,7 +106,7 @@ struct Run {
 
     Run(dg_ctx *c_, DpState &S_) : c(c_), S(S_), s(c_->stream) { sweep_prepare(S, X); }
     int n_win() const { return (int)S.dwin_t.size() - 1; }
-    int32_t *state_ptr(int level) const { return (int32_t *)(S.d_ring.as<char>() + (size_t)(level & (RING - 1)) * S.state_alloc_bytes) + S.pad_front; }
+    int32_t *state_ptr(int level) const { return (int32_t *)(S.d_ring.as<char>() + (size_t)(level & S.ring_mask()) * S.state_alloc_bytes) + S.pad_front; }
     size_t level_cells(int level) const {               // state size of a level (level 0: the source, k = 1)
         const int64_t k = level == 0 ? 1 : S.descs[level].k2;
         return (size_t)(k * k * S.RP);
@@ -115,7 +115,11 @@ struct Run {
 
     // issues the launches of destination levels [l0, l1) of the range that began at lb
     int issue_levels(int l0, int l1, int lb, int le) {
+#ifdef DG_CHAIN
         const bool chain = S.use_chain && !S.chain_failed && n_win() == 1 && (int)S.chain_host.size() == S.L;
+#else
+        const bool chain = false;
+#endif
         const int chain_max = (int)std::min<int64_t>(std::max<int64_t>(S.chain_max, 2), RING - 1);
         for (int l = l0; l < l1;) {
             if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);

@@ -17,6 +17,13 @@
 
 namespace dgi {
 
+// state slot of a level: ping-pong in the product build (a compile-time mask), a ring in the measurement build with chained dispatches
+#ifdef DG_CHAIN
+#define DG_SLOT(ARGS, LEVEL) ((LEVEL) & (ARGS).ring_mask)
+#else
+#define DG_SLOT(ARGS, LEVEL) ((LEVEL) & 1)
+#endif
+
 constexpr unsigned long long DIGEST_PRED_MUL = 0x9E3779B97F4A7C15ULL;   // oracle_dp.cpp: weight of the predecessor term
 
 __device__ __forceinline__ uint32_t ord_word(int i, int j, int wu, int wv) {
@@ -46,8 +53,8 @@ template <int RC, bool DIGEST>
 __device__ __forceinline__ void sweep_level_pairs(const SweepArgs &A, int lvl, int wave_id, int n_waves) {
     const LevelDesc d = A.descs[lvl];
     const int RP = A.RP;
-    const int32_t *__restrict__ cur = (const int32_t *)(A.ring + (size_t)((lvl - 1) & (RING - 1)) * A.slot_bytes + A.pad_bytes);
-    int32_t *__restrict__ nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
+    const int32_t *__restrict__ cur = (const int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl - 1) * A.slot_bytes + A.pad_bytes);
+    int32_t *__restrict__ nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
     const int lane = threadIdx.x & 63;
     const int nchunk = (RP + RC - 1) / RC;
     const int64_t ntask = (int64_t)d.k2 * d.ngroups * nchunk;
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(DG_PLAIN_WG) void dp_sweep_fast_kernel(const uint4 
     const int g = (int)blockIdx.x * DG_PLAIN_GW + (wv % DG_PLAIN_GW);    // always launched with DG_PLAIN_WG threads (reading blockDim would be a kernel-argument load)
     const int r0 = ((int)blockIdx.y * DG_PLAIN_CH + wv / DG_PLAIN_GW) * RC;
     if (g >= nblocks || r0 >= (rp_k & 0x1FFF)) return;                  // wave-uniform; no block barrier below
-    int32_t *nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
+    int32_t *nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
     sweep_task<RC, DIGEST, GENERAL, 0>(H, A, d, state_rsrc(cur, buf_bytes), nxt, (int)blockIdx.z, g, r0, lvl);
 }
 
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
                                                             FastArgs A, LevelDesc d, int lvl, const uint16_t *dm, int dT, const int32_t *__restrict__ heavy_rows) {
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, A.pad_bytes, dT, A.buf_bytes};
     publish_level(A.progress, lvl);
-    int32_t *nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
+    int32_t *nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
     const int r0 = (int)blockIdx.y * RC;                                // chunks of a row are neighbours in dispatch order: they share its delta row
     const int zc = 4 * n_heavy;
     if ((int)blockIdx.z < zc) {
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
     sweep_task<RC, DIGEST, GENERAL, 1>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, (int)blockIdx.z - zc, g, r0, lvl);
 }
 
+#ifdef DG_CHAIN
 // ---------------------------------------------------------------------------------------------
 // Chained dispatch: levels [l0, l0 + M) in ONE launch.  The level chain costs one kernel boundary per level (drain, L2 write-back,
 // barrier, dispatch ramp: about half of a level's 4 us); here the boundary between two levels is replaced by per-row completion
@@ -542,7 +550,8 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
 //   * M < RING: no state slot is written twice inside a dispatch, and everything older is behind a kernel boundary.
 // ---------------------------------------------------------------------------------------------
 template <int RC, bool DIGEST>
-__global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *__restrict__ lv, ChainDispatch D, FastArgs A, uint32_t *__restrict__ rowdone, int *abort_flag) {
+__global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *__restrict__ lv, ChainDispatch D, FastArgs A, uint32_t *__restrict__ rowdone, int *abort_flag,
+                                                             const LevelDesc *__restrict__ descs, const int32_t *__restrict__ heavy_rows) {
     __shared__ uint2 ex[3 * RC * 64];
     const uint32_t b = blockIdx.x;
     int q = 0;
@@ -551,13 +560,13 @@ __global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *_
     const int lvl = D.l0 + q;
     const uint32_t local = b - D.pre[q];
     const ChainLevel C = lv[lvl];
-    const LevelDesc d0 = A.descs[lvl];
+    const LevelDesc d0 = descs[lvl];
     LevelDesc d = d0;
     d.bp_nt = C.bp_nt;
     const uint32_t gxy = (uint32_t)(C.gx * C.gy);
     const int z = (int)(local / gxy), rem = (int)(local - (uint32_t)z * gxy), y = rem / C.gx, x = rem - y * C.gx;
-    const int32_t *cur = (const int32_t *)(A.ring + (size_t)((lvl - 1) & (RING - 1)) * A.slot_bytes);
-    int32_t *nxt = (int32_t *)(A.ring + (size_t)(lvl & (RING - 1)) * A.slot_bytes + A.pad_bytes);
+    const int32_t *cur = (const int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl - 1) * A.slot_bytes);
+    int32_t *nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
     const LevelHead H{C.rowrec_l, C.slots_l, C.rowx_l, cur, C.dm, C.rowx_stride, C.rp_k & 0x1FFF, C.rp_k >> 13, A.pad_bytes, C.dT, A.buf_bytes};
     if (local == 0 && threadIdx.x == 0) __hip_atomic_store(A.progress, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const ChainWait cw{rowdone + C.a0, C.expect_src, abort_flag};
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *_
         g = x * 4 + (z & 3);
         if (h < 4) row = (int)((C.heavy_lo >> (16 * h)) & 0xFFFFu);
         else if (h < HEAVY_INLINE) row = (int)((C.heavy_hi >> (16 * (h - 4))) & 0xFFFFu);
-        else row = A.heavy_rows[d.heavy_first + h];
+        else row = heavy_rows[d.heavy_first + h];
     } else {
         row = z - C.zc;
         g = x * 4 + wave;
@@ -607,6 +616,8 @@ __global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *_
     if (probe_on) D.probe[(size_t)lvl * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && !(D.dbg & 2)) __hip_atomic_fetch_add(rowdone + d.b0 + row, (uint32_t)weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+#endif  // DG_CHAIN
 
 // Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
 // levels through the memory-side Infinity Cache.  Every table byte is read exactly once per pass, so without this each
@@ -718,13 +729,12 @@ void sweep_prepare(const DpState &S, SweepLaunch &X) {
     A.descs = S.d_descs.as<LevelDesc>(); A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
     A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
     A.delta = A.delta_zero = S.d_delta.as<uint16_t>();
-    A.ring = S.d_ring.as<char>(); A.slot_bytes = S.state_alloc_bytes; A.pad_bytes = 4 * (size_t)S.pad_front;
+    A.ring = S.d_ring.as<char>(); A.slot_bytes = S.state_alloc_bytes; A.pad_bytes = 4 * (size_t)S.pad_front; A.ring_mask = S.ring_mask();
     A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
     FastArgs &F = X.F;
-    F.descs = A.descs; F.heavy_rows = S.d_heavy.as<int32_t>();
     F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.rowx = S.d_rowx.as<uint32_t>(); F.dead_cols = A.dead_cols;
     F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
-    F.ring = S.d_ring.as<char>(); F.slot_bytes = (uint32_t)S.state_alloc_bytes;
+    F.ring = S.d_ring.as<char>(); F.slot_bytes = (uint32_t)S.state_alloc_bytes; F.ring_mask = S.ring_mask();
 #ifdef DG_SWEEP_PROBE
     F.probe = S.d_probe.as<unsigned long long>();
 #endif
@@ -785,7 +795,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const uint4 *rowrec_l = F.rowrec + d.b0;
         const uint2 *slots_l = F.slots + d.slot_first;
         const uint32_t *rowx_l = F.rowx + d.rowx_off;
-        const int32_t *cur = (const int32_t *)(F.ring + (size_t)((l - 1) & (RING - 1)) * F.slot_bytes);
+        const int32_t *cur = (const int32_t *)(F.ring + (size_t)DG_SLOT(F, l - 1) * F.slot_bytes);
         const int dT = d.delta_off >= 0 ? d.T : 0;
         const uint16_t *dm = dT ? F.delta + d.delta_off - (int64_t)d.in_base * dT : F.delta_zero;   // (F.delta is biased by the resident delta window)
         const int rp_k = S.RP | (d.k << 13);
@@ -819,6 +829,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
     }
 }
 
+#ifdef DG_CHAIN
 // ---- chained dispatches (dp_sweep_chain_kernel) ----
 // cooperative workgroups for the level's fan-in rows at a given chunk size?  (the cost model of choose_rc at a fixed RC)
 static bool chain_coop(const DpState &S, const LevelDesc &d, int l, int rc) {
@@ -889,12 +900,18 @@ void sweep_launch_chain(DpState &S, SweepLaunch &X, int l0, int M, hipStream_t s
     int *abort_flag = &S.d_pfctl.as<PfCtl>()->chain_abort;
     S.launch_hist[63 * 4 + 3]++;
     S.levels_chained += M;
-#define DG_CHAIN(RCV, DG) hipLaunchKernelGGL((dp_sweep_chain_kernel<RCV, DG>), dim3(run), dim3(256), 0, s, lv, D, X.F, rowdone, abort_flag)
+#define DG_CHAIN(RCV, DG) hipLaunchKernelGGL((dp_sweep_chain_kernel<RCV, DG>), dim3(run), dim3(256), 0, s, lv, D, X.F, rowdone, abort_flag, S.d_descs.as<LevelDesc>(), S.d_heavy.as<int32_t>())
 #define DG_CHAIN_RC(DG) do { switch (rc) { case 1: DG_CHAIN(1, DG); break; case 2: DG_CHAIN(2, DG); break; case 3: DG_CHAIN(3, DG); break; default: DG_CHAIN(4, DG); break; } } while (0)
     if (S.want_digest) DG_CHAIN_RC(true); else DG_CHAIN_RC(false);
 #undef DG_CHAIN_RC
 #undef DG_CHAIN
 }
+
+#else   // the product library is built without the chained dispatches (measured 3-6x slower): `make chain` builds them
+bool sweep_chain_ok(const DpState &, const SweepLaunch &, int) { return false; }
+int sweep_chain_prepare(DpState &, SweepLaunch &, hipStream_t) { return DG_OK; }
+void sweep_launch_chain(DpState &, SweepLaunch &, int, int, hipStream_t) {}
+#endif  // DG_CHAIN
 
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s) {   // graph tables of destination levels [q0, q1) -> Infinity Cache
     const LevelDesc &da = S.descs[q0], &db = S.descs[q1 - 1];
