@@ -60,6 +60,7 @@ SYMBOLS = [
     "dg_sketch_get_timing", "dg_sketch_reads_dev", "dg_sketch_count_dictionary_dev", "dg_sketch_merge_runs_dev",
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
     "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid", "dg_dp_get_table_digest", "dg_hip_versions", "dg_anchor_add_haplotype_sketched",
+    "dg_sketch_set_option", "dg_sketch_get_stat", "dg_sketch_count_rank_dictionary_dev",
 ]
 
 lib.dg_create.restype = C.c_void_p
@@ -95,6 +96,9 @@ lib.dg_sketch_merge_runs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c
 lib.dg_sketch_partition_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 lib.dg_sketch_rank_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
 lib.dg_sketch_histogram_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+lib.dg_sketch_count_rank_dictionary_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+lib.dg_sketch_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+lib.dg_sketch_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
 
 
 class HapGraph(C.Structure):
@@ -327,6 +331,14 @@ class Context:
         out = np.zeros(n, np.uint64)
         _check(lib.dg_hash_kmers(self.h, kmers, n, k, out.ctypes.data), "dg_hash_kmers")
         return out
+
+    def sketch_set_option(self, name, value):
+        _check(lib.dg_sketch_set_option(self.h, name.encode(), int(value)), "dg_sketch_set_option")
+
+    def sketch_stat(self, name):
+        v = C.c_int64(0)
+        _check(lib.dg_sketch_get_stat(self.h, name.encode(), C.byref(v)), "dg_sketch_get_stat")
+        return v.value
 
     def sketch_timing(self):
         t = SketchTiming()

@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
-#include "dg_internal.hpp"
+#include "dg_sketch.hpp"
 
 namespace dgi {
 
@@ -43,14 +43,10 @@ struct Tile {
     int32_t seq_id;
 };
 
-struct SketchState {
-    DevBuf d_bases, d_off, d_seq_tiles, d_seq_wins, d_seq_tile0, d_seq_win0, d_tiles, d_tile_cnt, d_tile_base, d_tile_sparse, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
-    dg_sketch_timing timing;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-};
 void sketch_state_free(SketchState *s) {
     if (!s) return;
     for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->h_status) (void)hipHostFree(s->h_status);
     delete s;
 }
 
@@ -179,13 +175,17 @@ __device__ __forceinline__ uint8_t code_byte(uint64_t code, int k, int t) {
 
 // ------------------------------------------------------------------ tile kernel
 // MODE 0: count emissions per tile; MODE 1: write hashes (+ aux: seq_id for reads, position for haplotypes) at tile_base;
-// MODE 2 (the one in use): both in one pass -- tile_base holds SPARSE offsets (prefix of windows per tile, an upper bound
+// MODE 2: both in one pass -- tile_base holds SPARSE offsets (prefix of windows per tile, an upper bound
 // of the emissions), a compaction kernel closes the gaps afterwards.  Two passes meant hashing everything twice.
+// MODE 3 (reads, the one in use): every minimizer goes straight into the bucket of its hash range (dg_sketch_spectrum.hip):
+// one returning atomic on the bucket's fill counter + two 8/4-byte stores per minimizer, hidden behind the kernel's ALU work.
+// bucket_mode (MODE 2 / 3, reads): a hash is emitted once per tile (the Sp_R semantics are per read, solver.cpp:526-546, so
+// a second emission of the same hash by the same read never counts) and reads of more than one tile carry bit 31 in their id.
 template <int MODE, bool AUX_IS_POS>
 __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict__ bases, const Tile *__restrict__ tiles,
                                                           int64_t n_tiles, int k, int w, int64_t *__restrict__ tile_cnt,
                                                           const int64_t *__restrict__ tile_base, uint64_t *__restrict__ out_hash,
-                                                          int64_t *__restrict__ out_aux, int lds_per_wave) {
+                                                          int64_t *__restrict__ out_aux, int lds_per_wave, int bucket_mode, BucketEmit be) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         }
     }
     WAVE_SYNC();
-    int64_t wbase = MODE >= 1 ? tile_base[tile_id] : 0;
+    int64_t wbase = (MODE == 1 || MODE == 2) ? tile_base[tile_id] : 0;
     int64_t total = 0;
+    const bool multi_tile = (int64_t)T.seq_len - k - w + 2 > TW;
     for (int j0 = has_prev; j0 < n_runs; j0 += 64) {
         const int j = j0 + lane;
         bool emit = false;
@@ -346,16 +347,27 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             H = run_h[j];
             p = wpos[run_w[j]];
             emit = H != (j == 0 ? UINT64_MAX : run_h[j - 1]);
+            if (!AUX_IS_POS && bucket_mode && emit)
+                for (int jj = (!has_prev && run_h[0] == UINT64_MAX) ? 1 : 0; jj < j - 1; ++jj) if (run_h[jj] == H) { emit = false; break; }   // (a first hash equal to the initial prev_hash is never emitted: solver.cpp:329)
         }
         const unsigned long long m = __ballot(emit);
-        if (MODE >= 1 && emit) {
+        if ((MODE == 1 || MODE == 2) && emit) {
             const int64_t slot = wbase + total + __popcll(m & ((1ULL << lane) - 1ULL));
             out_hash[slot] = H;
-            out_aux[slot] = AUX_IS_POS ? (int64_t)(km0 + p) : (int64_t)T.seq_id;
+            out_aux[slot] = AUX_IS_POS ? (int64_t)(km0 + p) : ((int64_t)T.seq_id | ((bucket_mode && multi_tile) ? (int64_t)1 << 31 : 0));
+        }
+        if (MODE == 3 && emit) {
+            const uint32_t b = (uint32_t)(H >> (64 - be.bbits));
+            const uint32_t pos = atomicAdd(&be.fill[b], 1u);
+            if (pos < be.stride) {
+                const size_t at = (size_t)b * be.stride + pos;
+                be.bk_hash[at] = H;
+                be.bk_read[at] = (uint32_t)T.seq_id | (multi_tile ? 1u << 31 : 0u);
+            }
         }
         total += __popcll(m);
     }
-    if (MODE != 1 && lane == 0) tile_cnt[tile_id] = total;
+    if ((MODE == 0 || MODE == 2) && lane == 0) tile_cnt[tile_id] = total;
 }
 
 // closes the gaps of the single-pass output: one wave per tile copies its cnt entries from the sparse to the dense offset
@@ -372,33 +384,35 @@ __global__ __launch_bounds__(256) void compact_tiles_kernel(const int64_t *__res
 // Tile descriptors are built on the device from the sequence offsets (a million reads: no 8 MB offset download, no host
 // loop, no 32 MB descriptor upload per call).  seq_count: per sequence its tiles and windows; after exclusive scans of
 // both, seq_fill writes the descriptors and the sparse output offsets (a tile emits at most one minimizer per window).
-__global__ void seq_count_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, int64_t *__restrict__ ntile, int64_t *__restrict__ nwin) {
+struct SeqCount { int64_t tiles, wins; };     // per sequence; after the exclusive scan: first tile / first window (entry n_seq = totals)
+struct SeqCountPlus { __host__ __device__ SeqCount operator()(const SeqCount &a, const SeqCount &b) const { return SeqCount{a.tiles + b.tiles, a.wins + b.wins}; } };
+__global__ void seq_count_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, SeqCount *__restrict__ cnt) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_seq) return;
     int64_t nw = 0;
     if (s < n_seq) nw = max((off[s + 1] - off[s]) - k - w + 2, (int64_t)0);      // solver.cpp:291 / 372: nothing if len < w+k-1
-    nwin[s] = nw;
-    ntile[s] = (nw + TW - 1) / TW;
+    cnt[s] = SeqCount{(nw + TW - 1) / TW, nw};
 }
-__global__ __launch_bounds__(256) void seq_fill_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, const int64_t *__restrict__ tile_first,
-                                                       const int64_t *__restrict__ win_first, Tile *__restrict__ tiles, int64_t *__restrict__ sparse) {
+__global__ __launch_bounds__(256) void seq_fill_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, const SeqCount *__restrict__ first,
+                                                       Tile *__restrict__ tiles, int64_t *__restrict__ sparse) {
     // short sequences (reads: one tile each): one thread per sequence; a long one (a haplotype) is strided by the whole grid
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     if (n_seq == 1) {
-        const int64_t len = off[1] - off[0], nw = win_first[1];
-        for (int64_t t = tid; t < tile_first[1]; t += nth) {
+        const int64_t len = off[1] - off[0], nw = first[1].wins, nt = first[1].tiles;
+        for (int64_t t = tid; t < nt; t += nth) {
             tiles[t] = Tile{off[0], (int32_t)len, (int32_t)(t * TW), (int32_t)min((int64_t)TW, nw - t * TW), 0};
             sparse[t] = t * TW;
         }
-        if (tid == 0) sparse[tile_first[1]] = nw;
+        if (tid == 0) sparse[nt] = nw;
         return;
     }
     for (int64_t s = tid; s <= n_seq; s += nth) {
-        if (s == n_seq) { sparse[tile_first[n_seq]] = win_first[n_seq]; break; }
-        const int64_t len = off[s + 1] - off[s], nw = win_first[s + 1] - win_first[s], t0 = tile_first[s];
+        const SeqCount f = first[s];
+        if (s == n_seq) { sparse[f.tiles] = f.wins; break; }
+        const int64_t len = off[s + 1] - off[s], nw = first[s + 1].wins - f.wins, t0 = f.tiles;
         for (int64_t q = 0; q * TW < nw; ++q) {
             tiles[t0 + q] = Tile{off[s], (int32_t)len, (int32_t)(q * TW), (int32_t)min((int64_t)TW, nw - q * TW), (int32_t)s};
-            sparse[t0 + q] = win_first[s] + q * TW;
+            sparse[t0 + q] = f.wins + q * TW;
         }
     }
 }
@@ -473,11 +487,22 @@ __global__ __launch_bounds__(256) void mult_hist_kernel(const int32_t *__restric
     for (int q = 0; q < 8; ++q) {
         unsigned int v = low[q];
         for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_down(v, sft);
-        if ((threadIdx.x & 63) == 0 && v && q < n_bins) atomicAdd(&hist[q], (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lh[q], v);           // per workgroup first: a global word takes ~88 atomics per microsecond
     }
     __syncthreads();
-    for (int q = 8 + threadIdx.x; q < HIST_LDS && q < n_bins; q += 256)
+    for (int q = threadIdx.x; q < HIST_LDS && q < n_bins; q += 256)
         if (lh[q]) atomicAdd(&hist[q], (unsigned long long)lh[q]);
+}
+
+// dict_count_kernel and dict_rank_kernel on the same list (one rank: the local spectrum is the global one): one binary search
+__global__ void dict_count_rank_kernel(const uint64_t *__restrict__ dict, int64_t n_dict, const uint64_t *__restrict__ hash,
+                                       const int32_t *__restrict__ cnt, int64_t n, int64_t base, int32_t *__restrict__ out, int64_t *__restrict__ rank1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dict) return;
+    const uint64_t key = dict[i];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (hash[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < n && hash[lo] == key) { out[i] += cnt[lo]; rank1[i] += base + lo + 1; }
 }
 
 // ------------------------------------------------------------------ host side
@@ -491,27 +516,23 @@ static size_t lds_per_wave(int k, int w) {
     return (b + 15) & ~(size_t)15;
 }
 
-// Runs the tile kernel (+ compaction) over device-resident bases and sequence offsets. On return d_hash/d_aux hold n_emit entries.
-template <bool AUX_IS_POS>
-static int run_tiles(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_emit) {
+// Tile descriptors for device-resident bases and sequence offsets (one synchronisation: the tile and window totals size
+// the launch and the arrays).
+static int prepare_tiles(dg_ctx *c, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_tiles, int64_t *n_windows) {
     SketchState &S = state(c);
     hipStream_t s = c->stream;
-    *n_emit = 0;
+    *n_tiles = 0; *n_windows = 0;
     if (n_seq <= 0) return DG_OK;
-    // per-sequence tile / window counts and their exclusive scans (entry n_seq = totals)
-    if (int rc = S.d_seq_tiles.ensure(8 * (size_t)(n_seq + 1))) return rc;
-    if (int rc = S.d_seq_wins.ensure(8 * (size_t)(n_seq + 1))) return rc;
-    if (int rc = S.d_seq_tile0.ensure(8 * (size_t)(n_seq + 1))) return rc;
-    if (int rc = S.d_seq_win0.ensure(8 * (size_t)(n_seq + 1))) return rc;
-    hipLaunchKernelGGL(seq_count_kernel, dim3((unsigned)((n_seq + 1 + 255) / 256)), dim3(256), 0, s, off_dev, n_seq, k, w, S.d_seq_tiles.as<int64_t>(), S.d_seq_wins.as<int64_t>());
+    // per-sequence tile / window counts and their exclusive scan (entry n_seq = totals): one scan of the pair
+    if (int rc = S.d_seq_tiles.ensure(sizeof(SeqCount) * (size_t)(n_seq + 1))) return rc;
+    if (int rc = S.d_seq_tile0.ensure(sizeof(SeqCount) * (size_t)(n_seq + 1))) return rc;
+    hipLaunchKernelGGL(seq_count_kernel, dim3((unsigned)((n_seq + 1 + 255) / 256)), dim3(256), 0, s, off_dev, n_seq, k, w, S.d_seq_tiles.as<SeqCount>());
     size_t tb = 0;
-    DG_HIP(rocprim::exclusive_scan(nullptr, tb, S.d_seq_tiles.as<int64_t>(), S.d_seq_tile0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
+    DG_HIP(rocprim::exclusive_scan(nullptr, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
     if (int rc = S.d_tmp.ensure(tb)) return rc;
-    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_tiles.as<int64_t>(), S.d_seq_tile0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
-    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_wins.as<int64_t>(), S.d_seq_win0.as<int64_t>(), (int64_t)0, (size_t)(n_seq + 1), rocprim::plus<int64_t>(), s));
+    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
     int64_t tot[2] = {0, 0};
-    DG_HIP(hipMemcpyAsync(&tot[0], S.d_seq_tile0.as<int64_t>() + n_seq, 8, hipMemcpyDeviceToHost, s));
-    DG_HIP(hipMemcpyAsync(&tot[1], S.d_seq_win0.as<int64_t>() + n_seq, 8, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(tot, S.d_seq_tile0.as<SeqCount>() + n_seq, 16, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
     const int64_t nt = tot[0], n_win = tot[1];
     if (nt == 0) return DG_OK;
@@ -520,16 +541,48 @@ static int run_tiles(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, i
     if (int rc = S.d_tile_base.ensure(8 * (nt + 1))) return rc;
     if (int rc = S.d_tile_sparse.ensure(8 * (nt + 1))) return rc;
     hipLaunchKernelGGL(seq_fill_kernel, dim3((unsigned)std::min<int64_t>(((n_seq == 1 ? nt : n_seq + 1) + 255) / 256, 4096)), dim3(256), 0, s, off_dev, n_seq, k, w,
-                       S.d_seq_tile0.as<int64_t>(), S.d_seq_win0.as<int64_t>(), S.d_tiles.as<Tile>(), S.d_tile_sparse.as<int64_t>());
+                       S.d_seq_tile0.as<SeqCount>(), S.d_tiles.as<Tile>(), S.d_tile_sparse.as<int64_t>());
+    DG_HIP(hipGetLastError());
+    *n_tiles = nt; *n_windows = n_win;
+    return DG_OK;
+}
+
+// The tile kernel, sparse form: on return tile t's minimizers are the d_tile_cnt[t] entries at d_tile_sparse[t] of d_hash2 /
+// d_aux2 (a tile emits at most one per window, so the slots never collide).
+template <bool AUX_IS_POS>
+static int launch_tiles_sparse(dg_ctx *c, const char *bases_dev, int64_t nt, int64_t n_win, int k, int w, int bucket_mode) {
+    SketchState &S = state(c);
+    if (nt == 0) return DG_OK;
     if (int rc = S.d_hash2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;     // sparse output (dead before the sort reuses them)
     if (int rc = S.d_aux2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;
     const size_t lpw = lds_per_wave(k, w);
-    const unsigned grid = (unsigned)((nt + 3) / 4);
-    hipLaunchKernelGGL((sketch_tile_kernel<2, AUX_IS_POS>), dim3(grid), dim3(256), 4 * lpw, s, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
-                       S.d_tile_cnt.as<int64_t>(), S.d_tile_sparse.as<int64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), (int)lpw);
+    hipLaunchKernelGGL((sketch_tile_kernel<2, AUX_IS_POS>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       S.d_tile_cnt.as<int64_t>(), S.d_tile_sparse.as<int64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), (int)lpw, bucket_mode, BucketEmit{});
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+// The tile kernel, bucket form (reads): minimizers go straight into the buckets `be` describes
+static int launch_tiles_buckets(dg_ctx *c, const char *bases_dev, int64_t nt, int k, int w, const BucketEmit &be) {
+    SketchState &S = state(c);
+    if (nt == 0) return DG_OK;
+    const size_t lpw = lds_per_wave(k, w);
+    hipLaunchKernelGGL((sketch_tile_kernel<3, false>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       (int64_t *)nullptr, (const int64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr, (int)lpw, 1, be);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
+// closes the gaps of the sparse output: on return d_hash / d_aux hold the n_emit minimizers in sequence order
+static int compact_tiles(dg_ctx *c, int64_t nt, int64_t *n_emit) {
+    SketchState &S = state(c);
+    hipStream_t s = c->stream;
+    *n_emit = 0;
+    if (nt == 0) return DG_OK;
     // exclusive scan of counts (as int64) -> tile_base; total at [nt]
     DG_HIP(hipMemsetAsync((char *)S.d_tile_cnt.p + 8 * nt, 0, 8, s));
     const int64_t *in = S.d_tile_cnt.as<int64_t>();
+    size_t tb = 0;
     DG_HIP(rocprim::exclusive_scan(nullptr, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
     if (int rc = S.d_tmp.ensure(tb)) return rc;
     DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, in, S.d_tile_base.as<int64_t>(), (int64_t)0, (size_t)(nt + 1), rocprim::plus<int64_t>(), s));
@@ -540,10 +593,19 @@ static int run_tiles(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, i
     if (total == 0) return DG_OK;
     if (int rc = S.d_hash.ensure(8 * total)) return rc;
     if (int rc = S.d_aux.ensure(8 * total)) return rc;
-    hipLaunchKernelGGL(compact_tiles_kernel, dim3(grid), dim3(256), 0, s, S.d_tile_sparse.as<int64_t>(), S.d_tile_base.as<int64_t>(), S.d_tile_cnt.as<int64_t>(),
+    hipLaunchKernelGGL(compact_tiles_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, s, S.d_tile_sparse.as<int64_t>(), S.d_tile_base.as<int64_t>(), S.d_tile_cnt.as<int64_t>(),
                        nt, S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), S.d_hash.as<uint64_t>(), S.d_aux.as<int64_t>());
     DG_HIP(hipGetLastError());
     return DG_OK;
+}
+
+template <bool AUX_IS_POS>
+static int run_tiles(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_emit) {
+    int64_t nt = 0, n_win = 0;
+    *n_emit = 0;
+    if (int rc = prepare_tiles(c, off_dev, n_seq, k, w, &nt, &n_win)) return rc;
+    if (int rc = launch_tiles_sparse<AUX_IS_POS>(c, bases_dev, nt, n_win, k, w, 0)) return rc;
+    return compact_tiles(c, nt, n_emit);
 }
 
 // (hash, read) pairs in d_hash/d_aux -> sorted distinct hashes + #reads in d_uniq/d_cnt; returns n_distinct
@@ -590,16 +652,54 @@ static int events(SketchState &S) {
     return DG_OK;
 }
 
-static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_reads, int k, int w, int64_t *n_distinct) {
+// out_hash == nullptr: the spectrum stays in d_uniq / d_cnt (host API); otherwise it is written to the caller's device buffers.
+// Route: minimizers straight into hash-range buckets (MODE 3) -> if a bucket runs over its stride, the exact two-pass
+// placement from the sparse output -> if that is not possible either, the generic sort of all pairs.
+static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *off_dev, int64_t n_reads, int k, int w, uint64_t *out_hash,
+                               int32_t *out_cnt, int64_t cap, int64_t *n_distinct) {
     SketchState &S = state(c);
+    hipStream_t s = c->stream;
     if (int rc = events(S)) return rc;
-    DG_HIP(hipEventRecord(S.ev[0], c->stream));
-    int64_t n_emit = 0;
-    if (int rc = run_tiles<false>(c, bases_dev, off_dev, n_reads, k, w, &n_emit)) return rc;
-    DG_HIP(hipEventRecord(S.ev[1], c->stream));
-    if (int rc = spectrum_from_pairs(c, n_emit, n_distinct)) return rc;
-    DG_HIP(hipEventRecord(S.ev[2], c->stream));
-    DG_HIP(hipStreamSynchronize(c->stream));
+    DG_HIP(hipEventRecord(S.ev[0], s));
+    int64_t n_emit = 0, nt = 0, n_win = 0;
+    *n_distinct = 0;
+    S.stat_overflow = 0; S.stat_buckets = 0; S.stat_path = 2;
+    if (int rc = prepare_tiles(c, off_dev, n_reads, k, w, &nt, &n_win)) return rc;
+    BucketPlan plan;
+    bucket_plan(S, n_reads, nt, n_win, w, &plan);
+    bool done = nt == 0, ev1 = false;
+    if (!done && plan.ok && S.opt_mode == 0 && !S.sticky_exact) {
+        BucketEmit be;
+        if (int rc = bucket_fast_begin(c, S, plan, &be)) return rc;
+        if (int rc = launch_tiles_buckets(c, bases_dev, nt, k, w, be)) return rc;
+        DG_HIP(hipEventRecord(S.ev[1], s)); ev1 = true;
+        int outcome = 0;
+        if (int rc = bucket_finish(c, S, plan, true, out_hash, out_cnt, cap, n_distinct, &n_emit, &outcome)) return rc;
+        if (outcome == 0) { done = true; S.stat_path = 0; }
+        else if (outcome == 1) S.sticky_exact = true;                  // this ctx's read sets have hashes too frequent for the stride
+        else plan.ok = false;
+    }
+    if (!done && plan.ok && S.opt_mode != 1) {
+        if (int rc = launch_tiles_sparse<false>(c, bases_dev, nt, n_win, k, w, 1)) return rc;
+        if (!ev1) { DG_HIP(hipEventRecord(S.ev[1], s)); ev1 = true; }
+        if (int rc = bucket_exact_scatter(c, S, plan, nt)) return rc;
+        int outcome = 0;
+        if (int rc = bucket_finish(c, S, plan, false, out_hash, out_cnt, cap, n_distinct, &n_emit, &outcome)) return rc;
+        if (outcome == 0) { done = true; S.stat_path = 1; }
+    }
+    if (!done) {                                                       // generic path: stable 64-bit sort + run flags + reduce by key
+        if (int rc = launch_tiles_sparse<false>(c, bases_dev, nt, n_win, k, w, 0)) return rc;
+        if (!ev1) { DG_HIP(hipEventRecord(S.ev[1], s)); ev1 = true; }
+        if (int rc = compact_tiles(c, nt, &n_emit)) return rc;
+        if (int rc = spectrum_from_pairs(c, n_emit, n_distinct)) return rc;
+        if (out_hash && *n_distinct && *n_distinct <= cap) {
+            DG_HIP(hipMemcpyAsync(out_hash, S.d_uniq.p, 8 * (size_t)*n_distinct, hipMemcpyDeviceToDevice, s));
+            DG_HIP(hipMemcpyAsync(out_cnt, S.d_cnt.p, 4 * (size_t)*n_distinct, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (!ev1) DG_HIP(hipEventRecord(S.ev[1], s));
+    DG_HIP(hipEventRecord(S.ev[2], s));
+    DG_HIP(hipStreamSynchronize(s));
     DG_HIP(hipEventElapsedTime(&S.timing.kernel_ms, S.ev[0], S.ev[1]));
     DG_HIP(hipEventElapsedTime(&S.timing.sort_ms, S.ev[1], S.ev[2]));
     DG_HIP(hipEventElapsedTime(&S.timing.total_ms, S.ev[0], S.ev[2]));
@@ -623,7 +723,7 @@ extern "C" int dg_sketch_reads(dg_ctx *c, const char *bases, const int64_t *read
     if (int rc = S.d_off.ensure(8 * (size_t)(n_reads + 1))) return rc;
     if (n_reads) DG_HIP(hipMemcpyAsync(S.d_off.p, read_off, 8 * (size_t)(n_reads + 1), hipMemcpyHostToDevice, c->stream));
     int64_t nd = 0;
-    if (int rc = sketch_reads_device(c, S.d_bases.as<char>(), S.d_off.as<int64_t>(), n_reads, k, w, &nd)) return rc;
+    if (int rc = sketch_reads_device(c, S.d_bases.as<char>(), S.d_off.as<int64_t>(), n_reads, k, w, nullptr, nullptr, 0, &nd)) return rc;
     *hash = (uint64_t *)malloc(8 * (size_t)(nd + 1));
     *cnt = (int32_t *)malloc(4 * (size_t)(nd + 1));
     if (!*hash || !*cnt) { set_error("host malloc failed"); return DG_ERR_OOM; }
@@ -643,15 +743,34 @@ extern "C" int dg_sketch_reads_dev(dg_ctx *c, const char *bases_dev, const int64
     if (!bases_dev || !read_off_dev || !n_distinct || n_reads < 0) { set_error("dg_sketch_reads_dev: bad arguments"); return DG_ERR_ARG; }
     (void)n_bases;
     int64_t nd = 0;
-    if (int rc = sketch_reads_device(c, bases_dev, read_off_dev, n_reads, k, w, &nd)) return rc;
+    if (!hash_dev || !count_dev || cap < 0) { set_error("dg_sketch_reads_dev: bad output arguments"); return DG_ERR_ARG; }
+    if (int rc = sketch_reads_device(c, bases_dev, read_off_dev, n_reads, k, w, hash_dev, count_dev, cap, &nd)) return rc;
     if (nd > cap) { set_error("dg_sketch_reads_dev: %lld distinct hashes exceed capacity %lld", (long long)nd, (long long)cap); return DG_ERR_ARG; }
-    SketchState &S = state(c);
-    if (nd) {
-        DG_HIP(hipMemcpyAsync(hash_dev, S.d_uniq.p, 8 * (size_t)nd, hipMemcpyDeviceToDevice, c->stream));
-        DG_HIP(hipMemcpyAsync(count_dev, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToDevice, c->stream));
-        DG_HIP(hipStreamSynchronize(c->stream));
-    }
     *n_distinct = nd;
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_set_option(dg_ctx *c, const char *name, int64_t value) {
+    if (int rc = bind(c)) return rc;
+    if (!name) { set_error("dg_sketch_set_option: null name"); return DG_ERR_ARG; }
+    SketchState &S = state(c);
+    const std::string n(name);
+    if (n == "spectrum_mode") { if (value < 0 || value > 2) { set_error("spectrum_mode must be 0, 1 or 2"); return DG_ERR_ARG; } S.opt_mode = (int)value; S.sticky_exact = false; }
+    else if (n == "bucket_bits") { if (value < 0 || value > 15) { set_error("bucket_bits must be 0 (automatic) .. 15"); return DG_ERR_ARG; } S.opt_bucket_bits = (int)value; }
+    else if (n == "bucket_stride") { if (value < 0 || value > (1 << 20)) { set_error("bucket_stride out of range"); return DG_ERR_ARG; } S.opt_stride = (int)value; S.sticky_exact = false; }
+    else if (n == "residual_cap") { if (value < -1 || value > 1024) { set_error("residual_cap must be -1 (none) .. 1024, 0 = default"); return DG_ERR_ARG; } S.opt_residual_cap = (int)value; }
+    else { set_error("dg_sketch_set_option: unknown option '%s'", name); return DG_ERR_ARG; }
+    return DG_OK;
+}
+
+extern "C" int dg_sketch_get_stat(dg_ctx *c, const char *name, int64_t *value) {
+    if (!c || !c->sk || !name || !value) { set_error("dg_sketch_get_stat: no state"); return DG_ERR_STATE; }
+    const SketchState &S = *c->sk;
+    const std::string n(name);
+    if (n == "spectrum_path") *value = S.stat_path;                    // 0 buckets filled by the tile kernel, 1 buckets placed from the sparse output, 2 generic sort
+    else if (n == "buckets") *value = S.stat_buckets;
+    else if (n == "overflow_buckets") *value = S.stat_overflow;
+    else { set_error("dg_sketch_get_stat: unknown name '%s'", name); return DG_ERR_ARG; }
     return DG_OK;
 }
 
@@ -777,11 +896,21 @@ extern "C" int dg_sketch_rank_dictionary_dev(dg_ctx *c, const uint64_t *dict_dev
     return DG_OK;
 }
 
+extern "C" int dg_sketch_count_rank_dictionary_dev(dg_ctx *c, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev,
+                                                   const int32_t *count_dev, int64_t n, int64_t base, int32_t *counts_dev, int64_t *rank1_dev) {
+    if (int rc = bind(c)) return rc;
+    if (n_dict <= 0) return DG_OK;
+    hipLaunchKernelGGL(dict_count_rank_kernel, dim3((unsigned)((n_dict + 255) / 256)), dim3(256), 0, c->stream, dict_dev, n_dict, hash_dev, count_dev, n, base,
+                       counts_dev, rank1_dev);
+    DG_HIP(hipGetLastError());
+    return DG_OK;
+}
+
 extern "C" int dg_sketch_histogram_dev(dg_ctx *c, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev) {
     if (int rc = bind(c)) return rc;
     if (n_bins < 2 || !hist_dev) { set_error("dg_sketch_histogram_dev: bad arguments"); return DG_ERR_ARG; }
     if (n <= 0) return DG_OK;
-    hipLaunchKernelGGL(mult_hist_kernel, dim3((unsigned)std::min<int64_t>((n + 4095) / 4096, 1024)), dim3(256), 0, c->stream, count_dev, n, n_bins, (unsigned long long *)hist_dev);
+    hipLaunchKernelGGL(mult_hist_kernel, dim3((unsigned)std::min<int64_t>((n + 8191) / 8192, 256)), dim3(256), 0, c->stream, count_dev, n, n_bins, (unsigned long long *)hist_dev);
     DG_HIP(hipGetLastError());
     return DG_OK;
 }

@@ -86,6 +86,13 @@ class HipOps:
         self.capi._check(self.capi.lib.dg_sketch_rank_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), h.numel(), 0,
                                                                      rank1.data_ptr()), "dg_sketch_rank_dictionary_dev")
 
+    def count_rank_dictionary(self, dict_t, h, c, rank1):
+        """count_dictionary + rank_dictionary against the same list (one rank): one binary search per dictionary hash"""
+        counts = torch.zeros(dict_t.numel(), dtype=torch.int32, device=self.device)
+        self.capi._check(self.capi.lib.dg_sketch_count_rank_dictionary_dev(self.ctx.h, dict_t.data_ptr(), dict_t.numel(), h.data_ptr(), c.data_ptr(),
+                                                                           h.numel(), 0, counts.data_ptr(), rank1.data_ptr()), "dg_sketch_count_rank_dictionary_dev")
+        return counts
+
     def histogram(self, c, hist):
         self.capi._check(self.capi.lib.dg_sketch_histogram_dev(self.ctx.h, c.data_ptr(), c.numel(), hist.numel(), hist.data_ptr()), "dg_sketch_histogram_dev")
 
@@ -162,10 +169,19 @@ class ShardedSketch:
             torch.cuda.synchronize(); self._t = time.perf_counter()
         h, c = ops.sketch_reads(bases_t, off_t, k, w)
         self._lap("sketch")
+        multi = W > 1 or (self.force_exchange and dist.is_initialized())
+        if not multi and hasattr(ops, "count_rank_dictionary"):
+            # one rank: the local spectrum is the global one -- dictionary counts and ids from one pass, no size exchange
+            M = dict_t.numel()
+            tail = torch.zeros(HIST_BINS + M, dtype=torch.int64, device=self.device)
+            counts = ops.count_rank_dictionary(dict_t, h, c, tail[HIST_BINS:])
+            ops.histogram(c, tail[:HIST_BINS])
+            self._lap("count + rank dictionary, histogram")
+            n = int(h.numel())
+            return Score(counts=counts, ids=tail[HIST_BINS:] - 1, n_distinct=n, hist=tail[:HIST_BINS], range_hash=h, range_count=c, range_base=0, range_sizes=[n])
         counts = ops.count_dictionary(dict_t, h, c)
         self._lap("count_dictionary")
         work = None
-        multi = W > 1 or (self.force_exchange and dist.is_initialized())
         if multi:                                        # (1) hit vector: asynchronous, overlaps the exchange
             counts_c = self._c(counts)
             work = dist.all_reduce(counts_c, op=dist.ReduceOp.SUM, async_op=True)

@@ -150,6 +150,19 @@ void dg_free(void *);
 
 typedef struct dg_sketch_timing { float kernel_ms, sort_ms, total_ms; int64_t n_emitted; } dg_sketch_timing;
 int dg_sketch_get_timing(dg_ctx *, dg_sketch_timing *);
+/* parity / test knobs of the read spectrum (Sp_R, src/solver.cpp:526-546; none is needed in normal use):
+ *   spectrum_mode m        0 (default): the tile kernel drops every minimizer into the bucket of its hash range, one LDS table
+ *                          per bucket resolves it (dg_sketch_spectrum.hip); a bucket over its stride repeats the pass with
+ *                          exact placement.  2: exact placement at once.  1: the generic path, a stable 64-bit radix sort of
+ *                          all (hash, read) pairs + reduce-by-key.  The output is the same bit for bit.
+ *   bucket_bits b          0 (default): buckets sized to the input; 1..15: 2^b buckets
+ *   bucket_stride n        0 (default): 12288 slots per bucket in mode 0
+ *   residual_cap n         0 (default): 1024 residual entries per bucket (third hashes of a table entry, pairs of reads of
+ *                          several tiles); fewer (-1: none) leave more buckets to the host's per-segment finish
+ * dg_sketch_get_stat names, about the last dg_sketch_reads / dg_sketch_reads_dev call: spectrum_path (0 buckets filled by the
+ * tile kernel, 1 exact placement, 2 generic), buckets, overflow_buckets (finished by the host per segment) */
+int dg_sketch_set_option(dg_ctx *, const char *name, int64_t value);
+int dg_sketch_get_stat(dg_ctx *, const char *name, int64_t *value);
 
 /* Device-resident variants for the read-sharded multi-GPU path (one rank per GPU; collectives are
  * done by the caller over RCCL on the same buffers).
@@ -178,6 +191,10 @@ int dg_sketch_partition_dev(dg_ctx *, const uint64_t *hash_dev, int64_t n, int w
  * (solver.cpp:541-546), -1 = not a read minimizer.  Asynchronous on the ctx stream. */
 int dg_sketch_rank_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev, int64_t n,
                                   int64_t base, int64_t *rank1_dev);
+/* dg_sketch_count_dictionary_dev and dg_sketch_rank_dictionary_dev against the SAME list in one pass (one rank: the local
+ * spectrum is the global one).  Asynchronous. */
+int dg_sketch_count_rank_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n_dict, const uint64_t *hash_dev,
+                                        const int32_t *count_dev, int64_t n, int64_t base, int32_t *counts_dev, int64_t *rank1_dev);
 /* hist_dev[min(count, n_bins-1)] += 1 per entry: this range's share of Hist_kmer (solver.cpp:745-755).  Asynchronous. */
 int dg_sketch_histogram_dev(dg_ctx *, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev);
 

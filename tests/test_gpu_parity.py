@@ -62,6 +62,92 @@ def test_sketch_reads_vs_oracle(gpu_ctx, k, w):
     assert np.all(np.diff(hg.astype(np.uint64)) > 0)          # globally sorted, distinct
 
 
+SPECTRUM_MODES = {          # name: (options, spectrum_path expected: 0 tile kernel fills the buckets, 1 exact placement, 2 generic sort)
+    "buckets": ({}, 0),
+    "generic": ({"spectrum_mode": 1}, 2),
+    "exact_placement": ({"spectrum_mode": 2}, 1),
+    "two_buckets": ({"bucket_bits": 1, "bucket_stride": 1 << 20}, 0),
+    "32k_buckets": ({"bucket_bits": 15, "bucket_stride": 4096}, 0),
+    "stride_overrun": ({"bucket_bits": 4, "bucket_stride": 512}, 1),                 # a bucket runs over its stride: repeated with exact placement
+    "host_segments": ({"bucket_bits": 3, "bucket_stride": 1 << 17, "residual_cap": 1}, 0),                       # residual lists overflow: those buckets are finished per segment with rocPRIM
+    "host_segments_exact": ({"spectrum_mode": 2, "bucket_bits": 3, "residual_cap": 1}, 1),
+    "no_residual": ({"bucket_bits": 9, "residual_cap": -1}, 2),                      # > 256 buckets would need the host: the generic sort after all
+}
+
+
+def _spectrum_reads(rng):
+    reads = [_rnd(rng, 150) for _ in range(4000)]
+    genome = _rnd(rng, 30000)
+    reads += [genome[s:s + 150] for s in rng.integers(0, len(genome) - 150, 6000)]          # 30x: runs of ~20 reads per hash
+    x, y = _rnd(rng, 500), _rnd(rng, 700)
+    reads += [x + y + x, x + x + x + y, y + synth.revcomp(y)]                                 # the same hash in several tiles of one read
+    reads += [x[:60] + x[:60] + x[:40], y[:75] + synth.revcomp(y[:75])]                       # ... and twice in one tile
+    reads += [genome[s:s + 300] for s in rng.integers(0, len(genome) - 300, 300)]             # two-tile reads: their pairs go through the residual lists
+    reads += [reads[5]] * 700 + [b"", b"ACGT", _rnd(rng, 300, b"ACGTN"), b"A" * 400, b"AC" * 200]
+    return reads
+
+
+def _reset_spectrum_options(ctx):
+    for key in ("spectrum_mode", "bucket_bits", "bucket_stride", "residual_cap"):
+        ctx.sketch_set_option(key, 0)
+
+
+@pytest.mark.parametrize("mode", list(SPECTRUM_MODES))
+def test_sketch_spectrum_paths_agree(gpu_ctx, mode):
+    """Sp_R from hash-range buckets resolved in LDS tables == the stable radix sort of all pairs == the oracle, in every
+    execution mode (who fills the buckets, bucket counts, residual lists finished by the host, the give-up routes)."""
+    rng = np.random.default_rng(4242)
+    reads = _spectrum_reads(rng)
+    ho, co = orc.sketch_reads(reads, 21, 11)
+    opts, want_path = SPECTRUM_MODES[mode]
+    try:
+        for key, v in opts.items():
+            gpu_ctx.sketch_set_option(key, v)
+        hg, cg = gpu_ctx.sketch_reads(reads, 21, 11)
+        path, ovf = gpu_ctx.sketch_stat("spectrum_path"), gpu_ctx.sketch_stat("overflow_buckets")
+    finally:
+        _reset_spectrum_options(gpu_ctx)
+    assert np.array_equal(hg, ho) and np.array_equal(cg, co)
+    assert path == want_path
+    if mode.startswith("host_segments"):
+        assert ovf > 0
+    if mode == "buckets":
+        assert ovf == 0
+
+
+def test_sketch_spectrum_heavy_hitters(gpu_ctx):
+    """a hash held by more reads than a bucket's stride (13,000 copies of one read): the pass is repeated with exact placement,
+    where a bucket may be any size, and this ctx keeps placing exactly afterwards"""
+    rng = np.random.default_rng(77)
+    one = _rnd(rng, 150)
+    reads = [_rnd(rng, 150) for _ in range(3000)] + [one] * 13000
+    ctx = capi.Context(0)
+    hg, cg = ctx.sketch_reads(reads, 31, 25)
+    assert ctx.sketch_stat("spectrum_path") == 1 and ctx.sketch_stat("overflow_buckets") == 0
+    ctx.sketch_reads(reads[:5000], 31, 25)
+    assert ctx.sketch_stat("spectrum_path") == 1
+    ctx.sketch_set_option("spectrum_mode", 1)
+    h2, c2 = ctx.sketch_reads(reads, 31, 25)
+    assert np.array_equal(hg, h2) and np.array_equal(cg, c2)
+    ho, co = orc.sketch_reads(reads[:3000] + [one], 31, 25)
+    h1, c1 = orc.sketch_reads([one], 31, 25)
+    want = dict(zip(ho.tolist(), co.tolist()))
+    for h in h1.tolist():
+        want[h] += 12999
+    assert dict(zip(hg.tolist(), cg.tolist())) == want
+
+
+def test_sketch_spectrum_long_reads_take_the_generic_sort(gpu_ctx):
+    """read sets made of reads longer than one tile (128 windows) are left to the generic path: every pair of theirs would go
+    through the residual lists"""
+    rng = np.random.default_rng(9)
+    reads = [_rnd(rng, 400) for _ in range(500)]
+    hg, cg = gpu_ctx.sketch_reads(reads, 21, 11)
+    assert gpu_ctx.sketch_stat("spectrum_path") == 2
+    ho, co = orc.sketch_reads(reads, 21, 11)
+    assert np.array_equal(hg, ho) and np.array_equal(cg, co)
+
+
 def test_sketch_reads_empty_and_ragged(gpu_ctx):
     for reads in ([], [b""], [b"ACGT"], [b"", b"", b"ACGTACGT"]):
         h, c = gpu_ctx.sketch_reads(reads, 31, 25)
