@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     int64_t wbase = (MODE == 1 || MODE == 2) ? tile_base[tile_id] : 0;
     int64_t total = 0;
     const bool multi_tile = (int64_t)T.seq_len - k - w + 2 > TW;
+    const bool dedupe = !AUX_IS_POS && bucket_mode;
+    // a first hash equal to the initial prev_hash is never emitted (solver.cpp:329): it does not shadow later runs
+    const int a_first = (dedupe && !has_prev && run_h[0] == UINT64_MAX) ? 1 : 0;
     for (int j0 = has_prev; j0 < n_runs; j0 += 64) {
         const int j = j0 + lane;
         bool emit = false;
@@ -347,8 +350,19 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             H = run_h[j];
             p = wpos[run_w[j]];
             emit = H != (j == 0 ? UINT64_MAX : run_h[j - 1]);
-            if (!AUX_IS_POS && bucket_mode && emit)
-                for (int jj = (!has_prev && run_h[0] == UINT64_MAX) ? 1 : 0; jj < j - 1; ++jj) if (run_h[jj] == H) { emit = false; break; }   // (a first hash equal to the initial prev_hash is never emitted: solver.cpp:329)
+        }
+        if (dedupe) {                                                  // run j repeats the hash of an earlier run of this tile
+            // the kernel is issue-bound (~4 k cycles of its SIMD per tile), so this loop is scalar-controlled: two broadcast
+            // reads per round, compares against SGPR bounds
+            const int last = __builtin_amdgcn_readfirstlane(min(n_runs, j0 + 64) - 1), first = __builtin_amdgcn_readfirstlane(a_first);
+            bool dup = false;
+            int a = first;
+            for (; a + 1 < last; a += 2) {
+                const uint64_t x0 = run_h[a], x1 = run_h[a + 1];
+                dup |= ((x0 == H) & (a < j - 1)) | ((x1 == H) & (a + 1 < j - 1));
+            }
+            if (a < last) dup |= (run_h[a] == H) & (a < j - 1);
+            emit &= !dup;
         }
         const unsigned long long m = __ballot(emit);
         if ((MODE == 1 || MODE == 2) && emit) {

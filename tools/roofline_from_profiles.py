@@ -77,19 +77,33 @@ out = {
 }
 # ---- sketch (config-4 scoring pass on one rank)
 try:
-    sk = {r["Name"].split("(")[0].replace("void dgi::", "").replace("dgi::", ""): (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(f"{d}/sketch_kernel_stats.csv"))}
+    sk = {r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void dgi::", "").replace("dgi::", ""): (int(r["Calls"]), float(r["AverageNs"]))
+          for r in csv.DictReader(open(f"{d}/sketch_kernel_stats.csv"))}
+    tile_name = "sketch_tile_kernel<3, false>" if any("sketch_tile_kernel<3, false>" in k for k in sk) else "sketch_tile_kernel<2, false>"
+    tile = next(v for k, v in sk.items() if tile_name in k)
     sq = {}
     for r in csv.DictReader(open(f"{d}/sketch_pmc_sq.csv")):
-        if "sketch_tile_kernel" in r["kernel"]:
+        if tile_name in r["kernel"]:
             sq[r["counter"]] = float(r["sum"]) / int(r["dispatches"])
-    tile = next(v for k, v in sk.items() if "sketch_tile_kernel<2, false>" in k)
     valu_busy = sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sq["GRBM_GUI_ACTIVE"] / 8)
-    out["sketch"] = {"kernel": "sketch_tile_kernel<2, false>", "avg_ns": tile[1], "calls": tile[0], "bound": "valu",
+    out["sketch"] = {"kernel": tile_name, "avg_ns": tile[1], "calls": tile[0], "bound": "valu",
                      "counters_per_dispatch": sq, "valu_busy_frac": valu_busy,
-                     "valu_insts_per_base": sq["SQ_INSTS_VALU"] * 64 / (bench["sketch_config4"]["reads"] * 150) if "sketch_config4" in bench else None,
+                     "valu_wave_insts_per_read": sq["SQ_INSTS_VALU"] / bench["sketch_config4"]["reads"] if "sketch_config4" in bench else None,   # one wave per 150-bp read (one tile)
                      "wave_cycles_split": {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in sq},
                      "algorithmic_GBps": (1.0 + 8 * 2 / 26) * bench["sketch_config4"]["reads"] * 150 / tile[1] if "sketch_config4" in bench else None,
                      "source": "sketch_kernel_stats.csv / sketch_pmc_sq.csv: rocprofv3 over tools/score_profile.py (1,007,415 x 150-bp reads, one rank)"}
+    # the spectrum stage behind the tile kernel (round 2: rocPRIM sort + reduce; round 3: one LDS table per hash-range bucket)
+    tab = next((v for k, v in sk.items() if "bk_table_kernel" in k), None)
+    if tab and "sketch_config4" in bench:
+        pairs = sq.get("pairs") or 8.0e6                          # emitted (hash, read) pairs of the set (dg_sketch_timing.n_emitted: 7,996,5xx)
+        nd = bench["sketch_config4"]["distinct_hashes"]
+        alg = 20.0 * pairs + 12.0 * nd                            # pass 1 reads the hash, pass 2 hash + read; 12 B per distinct hash out
+        rest = {k: v for k, v in sk.items() if k.strip() in ("bk_dscan_kernel", "bk_gather_kernel")}
+        out["sketch_spectrum"] = {"kernel": "bk_table_kernel", "avg_ns": tab[1], "calls": tab[0], "bound": "hbm (nominal); LDS atomic latency in fact",
+                                  "algorithmic_bytes": alg, "achieved_GBps": alg / tab[1], "peak_GBps": PEAK, "frac": alg / tab[1] / PEAK,
+                                  "other_kernels_avg_ns": {k.strip(): v[1] for k, v in rest.items()},
+                                  "note": "one 1,024-lane workgroup per bucket (4,096 buckets of ~2 k pairs), 114 KB of LDS tables each: one workgroup per CU; "
+                                          "the second pass over the bucket hits L2; 5 % of the scoring pass"}
 except (OSError, KeyError, StopIteration, ZeroDivisionError) as e:
     out["sketch"] = {"error": repr(e)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
