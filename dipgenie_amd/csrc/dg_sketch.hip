@@ -398,14 +398,14 @@ __global__ __launch_bounds__(256) void compact_tiles_kernel(const int64_t *__res
 // Tile descriptors are built on the device from the sequence offsets (a million reads: no 8 MB offset download, no host
 // loop, no 32 MB descriptor upload per call).  seq_count: per sequence its tiles and windows; after exclusive scans of
 // both, seq_fill writes the descriptors and the sparse output offsets (a tile emits at most one minimizer per window).
-struct SeqCount { int64_t tiles, wins; };     // per sequence; after the exclusive scan: first tile / first window (entry n_seq = totals)
-struct SeqCountPlus { __host__ __device__ SeqCount operator()(const SeqCount &a, const SeqCount &b) const { return SeqCount{a.tiles + b.tiles, a.wins + b.wins}; } };
+struct SeqCount { int64_t tiles, wins, multi; };   // per sequence (multi: 1 if it has several tiles); after the exclusive scan: first tile / first window (entry n_seq = totals)
+struct SeqCountPlus { __host__ __device__ SeqCount operator()(const SeqCount &a, const SeqCount &b) const { return SeqCount{a.tiles + b.tiles, a.wins + b.wins, a.multi + b.multi}; } };
 __global__ void seq_count_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, SeqCount *__restrict__ cnt) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_seq) return;
     int64_t nw = 0;
     if (s < n_seq) nw = max((off[s + 1] - off[s]) - k - w + 2, (int64_t)0);      // solver.cpp:291 / 372: nothing if len < w+k-1
-    cnt[s] = SeqCount{(nw + TW - 1) / TW, nw};
+    cnt[s] = SeqCount{(nw + TW - 1) / TW, nw, nw > TW ? 1 : 0};
 }
 __global__ __launch_bounds__(256) void seq_fill_kernel(const int64_t *__restrict__ off, int64_t n_seq, int k, int w, const SeqCount *__restrict__ first,
                                                        Tile *__restrict__ tiles, int64_t *__restrict__ sparse) {
@@ -532,7 +532,7 @@ static size_t lds_per_wave(int k, int w) {
 
 // Tile descriptors for device-resident bases and sequence offsets (one synchronisation: the tile and window totals size
 // the launch and the arrays).
-static int prepare_tiles(dg_ctx *c, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_tiles, int64_t *n_windows) {
+static int prepare_tiles(dg_ctx *c, const int64_t *off_dev, int64_t n_seq, int k, int w, int64_t *n_tiles, int64_t *n_windows, int64_t *n_multi = nullptr) {
     SketchState &S = state(c);
     hipStream_t s = c->stream;
     *n_tiles = 0; *n_windows = 0;
@@ -542,12 +542,13 @@ static int prepare_tiles(dg_ctx *c, const int64_t *off_dev, int64_t n_seq, int k
     if (int rc = S.d_seq_tile0.ensure(sizeof(SeqCount) * (size_t)(n_seq + 1))) return rc;
     hipLaunchKernelGGL(seq_count_kernel, dim3((unsigned)((n_seq + 1 + 255) / 256)), dim3(256), 0, s, off_dev, n_seq, k, w, S.d_seq_tiles.as<SeqCount>());
     size_t tb = 0;
-    DG_HIP(rocprim::exclusive_scan(nullptr, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
+    DG_HIP(rocprim::exclusive_scan(nullptr, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
     if (int rc = S.d_tmp.ensure(tb)) return rc;
-    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
-    int64_t tot[2] = {0, 0};
-    DG_HIP(hipMemcpyAsync(tot, S.d_seq_tile0.as<SeqCount>() + n_seq, 16, hipMemcpyDeviceToHost, s));
+    DG_HIP(rocprim::exclusive_scan(S.d_tmp.p, tb, S.d_seq_tiles.as<SeqCount>(), S.d_seq_tile0.as<SeqCount>(), SeqCount{0, 0, 0}, (size_t)(n_seq + 1), SeqCountPlus(), s));
+    int64_t tot[3] = {0, 0, 0};
+    DG_HIP(hipMemcpyAsync(tot, S.d_seq_tile0.as<SeqCount>() + n_seq, 24, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
+    if (n_multi) *n_multi = tot[2];
     const int64_t nt = tot[0], n_win = tot[1];
     if (nt == 0) return DG_OK;
     if (int rc = S.d_tiles.ensure(sizeof(Tile) * nt)) return rc;
@@ -678,9 +679,10 @@ static int sketch_reads_device(dg_ctx *c, const char *bases_dev, const int64_t *
     int64_t n_emit = 0, nt = 0, n_win = 0;
     *n_distinct = 0;
     S.stat_overflow = 0; S.stat_buckets = 0; S.stat_path = 2;
-    if (int rc = prepare_tiles(c, off_dev, n_reads, k, w, &nt, &n_win)) return rc;
+    int64_t n_multi = 0;
+    if (int rc = prepare_tiles(c, off_dev, n_reads, k, w, &nt, &n_win, &n_multi)) return rc;
     BucketPlan plan;
-    bucket_plan(S, n_reads, nt, n_win, w, &plan);
+    bucket_plan(S, n_reads, nt, n_win, n_multi, w, &plan);
     bool done = nt == 0, ev1 = false;
     if (!done && plan.ok && S.opt_mode == 0 && !S.sticky_exact) {
         BucketEmit be;
@@ -772,6 +774,7 @@ extern "C" int dg_sketch_set_option(dg_ctx *c, const char *name, int64_t value) 
     if (n == "spectrum_mode") { if (value < 0 || value > 2) { set_error("spectrum_mode must be 0, 1 or 2"); return DG_ERR_ARG; } S.opt_mode = (int)value; S.sticky_exact = false; }
     else if (n == "bucket_bits") { if (value < 0 || value > 15) { set_error("bucket_bits must be 0 (automatic) .. 15"); return DG_ERR_ARG; } S.opt_bucket_bits = (int)value; }
     else if (n == "bucket_stride") { if (value < 0 || value > (1 << 20)) { set_error("bucket_stride out of range"); return DG_ERR_ARG; } S.opt_stride = (int)value; S.sticky_exact = false; }
+    else if (n == "host_buckets") { if (value < 0 || value > 256) { set_error("host_buckets must be 0 (default 256) .. 256"); return DG_ERR_ARG; } S.opt_host_buckets = (int)value; }
     else if (n == "residual_cap") { if (value < -1 || value > 1024) { set_error("residual_cap must be -1 (none) .. 1024, 0 = default"); return DG_ERR_ARG; } S.opt_residual_cap = (int)value; }
     else { set_error("dg_sketch_set_option: unknown option '%s'", name); return DG_ERR_ARG; }
     return DG_OK;

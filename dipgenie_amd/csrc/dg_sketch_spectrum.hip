@@ -35,6 +35,7 @@ namespace {
 constexpr int BT = 1024;                // lanes of a hist / scatter / table workgroup
 constexpr int STRIDE = 12288;           // slots per bucket when the tile kernel fills the buckets
 constexpr int RCAP = 1024;              // residual entries per bucket (one per lane)
+constexpr int SBITS_MIN = 12, SETCAP = 16384;   // hash-set slots of the multi-tile repeat filter at 2^12 table entries (64 of the tables' 112 KB)
 constexpr int SBITS = 12;               // table entries per bucket = 2^SBITS (112 KB of LDS: one workgroup per CU)
 constexpr int OVF_MAX = 256;            // buckets finished by the host one by one; more -> generic path
 constexpr int G_MAX = 256;              // hist / scatter workgroups (one per CU)
@@ -146,14 +147,14 @@ __global__ __launch_bounds__(BT) void bk_scatter_kernel(const int64_t *__restric
 struct Residual { uint64_t low; uint32_t sub, read; };
 __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_t *bk_read, const uint32_t *__restrict__ start,
                                                       const uint32_t *__restrict__ fill, uint32_t stride, int bbits, int sbits, uint32_t residual_cap,
-                                                      uint32_t *__restrict__ dcount, uint32_t *__restrict__ ovf) {
+                                                      int has_multi, uint32_t *__restrict__ dcount, uint32_t *__restrict__ ovf) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int nS = 1 << sbits, tid = threadIdx.x, b = blockIdx.x;
     unsigned long long *mn = (unsigned long long *)lds_raw, *mx = mn + nS;
     uint32_t *cm = (uint32_t *)(mx + nS), *cM = cm + nS, *nd = cM + nS;
     Residual *res = (Residual *)(nd + nS);
     uint8_t *rfl = (uint8_t *)(res + RCAP);
-    uint32_t *scr = (uint32_t *)(rfl + RCAP);                          // [0..16] scan, [20] residual count
+    uint32_t *scr = (uint32_t *)(rfl + RCAP);                          // [0..16] scan, [20] residual count, [21] hash-set entries
     size_t s;
     uint32_t n;
     if (stride) { s = (size_t)b * stride; n = fill[b]; if (n > stride) { if (tid == 0) { dcount[b] = 0; atomicAdd(&ovf[1], 1u); } return; } }
@@ -161,6 +162,35 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     if (n == 0) { if (tid == 0) dcount[b] = 0; return; }
     const int lowbits = 64 - bbits - sbits;
     const unsigned long long lowmask = (1ULL << lowbits) - 1ULL;
+    if (has_multi) {
+        // Pairs of reads longer than one tile (bit 31 of the read id): the same (hash, read) may have come from two tiles.  An
+        // LDS hash set of pair indices keeps one of each and clears its bit; the repeats keep theirs and are skipped below.
+        // (The set lives where the tables go afterwards.)
+        uint32_t *set = (uint32_t *)lds_raw;
+        const uint32_t cap = SETCAP << (sbits - SBITS_MIN), EMPTY = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < cap; i += BT) set[i] = EMPTY;
+        if (tid == 0) scr[21] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += BT) {
+            const uint32_t r = bk_read[s + i];
+            if (!(r >> 31)) continue;
+            const unsigned long long h = bk_hash[s + i];
+            unsigned long long m = (h ^ ((unsigned long long)(r & 0x7FFFFFFFu) * 0x9E3779B97F4A7C15ULL));
+            m ^= m >> 29; m *= 0xBF58476D1CE4E5B9ULL; m ^= m >> 32;
+            uint32_t slot = (uint32_t)m & (cap - 1);
+            for (uint32_t probe = 0; probe < cap; ++probe) {
+                const uint32_t old = atomicCAS(&set[slot], EMPTY, i);
+                if (old == EMPTY) { bk_read[s + i] = r & 0x7FFFFFFFu; atomicAdd(&scr[21], 1u); break; }
+                if (bk_hash[s + old] == h && ((bk_read[s + old] ^ r) & 0x7FFFFFFFu) == 0) break;
+                slot = (slot + 1) & (cap - 1);
+            }
+        }
+        __syncthreads();
+        if (scr[21] > cap / 2 + cap / 4) {                             // the set got too full to trust the probe bound: the host finishes the bucket
+            if (tid == 0) { dcount[b] = 0; const uint32_t o = atomicAdd(&ovf[0], 1u); if (o < OVF_MAX) ovf[2 + o] = (uint32_t)b; }
+            return;
+        }
+    }
     for (int i = tid; i < nS; i += BT) { mn[i] = ~0ULL; mx[i] = 0; cm[i] = 0; cM[i] = 0; nd[i] = 0; }
     if (tid == 0) scr[20] = 0;
     __syncthreads();
@@ -174,8 +204,9 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     for (uint32_t i = tid; i < n; i += BT) {
         const unsigned long long h = bk_hash[s + i], low = h & lowmask;
         const uint32_t sub = (uint32_t)(h >> lowbits) & (uint32_t)(nS - 1), r = bk_read[s + i];
-        if (!(r >> 31) && low == mn[sub]) atomicAdd(&cm[sub], 1u);
-        else if (!(r >> 31) && low == mx[sub]) atomicAdd(&cM[sub], 1u);
+        if (r >> 31) continue;                                         // a repeat of a (hash, read) counted elsewhere
+        if (low == mn[sub]) atomicAdd(&cm[sub], 1u);
+        else if (low == mx[sub]) atomicAdd(&cM[sub], 1u);
         else {
             const uint32_t x = atomicAdd(&scr[20], 1u);
             if (x < residual_cap) res[x] = Residual{low, sub, r};
@@ -183,40 +214,26 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     }
     __syncthreads();
     const uint32_t R = scr[20];
-    if (R > residual_cap) {                                            // nothing of the bucket has been overwritten: the host finishes it
+    if (R > residual_cap) {                                            // no result of the bucket has been written: the host finishes it
         if (tid == 0) { dcount[b] = 0; const uint32_t o = atomicAdd(&ovf[0], 1u); if (o < OVF_MAX) ovf[2 + o] = (uint32_t)b; }
         return;
     }
-    // residual entry of this lane: 1 a repeat of an earlier (hash, read) | 2 first entry of a third hash; its count and rank
+    // residual entry of this lane = a third hash of its table entry: the first of its hash speaks for it (count, rank)
     Residual me{0, 0, 0};
     uint32_t third_cnt = 0, third_rank = 0;
     bool third = false;
     if (R) {
-        uint8_t f = 0;
         if ((uint32_t)tid < R) {
             me = res[tid];
-            if (me.read >> 31)
-                for (uint32_t j = 0; j < (uint32_t)tid; ++j) if (res[j].read == me.read && res[j].sub == me.sub && res[j].low == me.low) { f = 1; break; }
-            rfl[tid] = f;
+            bool first = true;
+            for (uint32_t j = 0; j < R; ++j)
+                if (res[j].sub == me.sub && res[j].low == me.low) { if (j < (uint32_t)tid) first = false; ++third_cnt; }
+            if (first) { third = true; atomicAdd(&nd[me.sub], 1u); }
+            rfl[tid] = first ? 1 : 0;
         }
-        __syncthreads();
-        if ((uint32_t)tid < R && !f) {
-            if (me.low == mn[me.sub]) atomicAdd(&cm[me.sub], 1u);
-            else if (me.low == mx[me.sub]) atomicAdd(&cM[me.sub], 1u);
-            else {
-                bool first = true;
-                for (uint32_t j = 0; j < R; ++j) {
-                    if (rfl[j] & 1) continue;
-                    if (res[j].sub == me.sub && res[j].low == me.low) { if (j < (uint32_t)tid) first = false; ++third_cnt; }
-                }
-                if (first) { third = true; atomicAdd(&nd[me.sub], 1u); f = 2; }
-            }
-        }
-        __syncthreads();
-        if ((uint32_t)tid < R) rfl[tid] = f;
         __syncthreads();
         if (third)
-            for (uint32_t j = 0; j < R; ++j) if ((rfl[j] & 2) && res[j].sub == me.sub && res[j].low < me.low) ++third_rank;
+            for (uint32_t j = 0; j < R; ++j) if (rfl[j] && res[j].sub == me.sub && res[j].low < me.low) ++third_rank;
     }
     // places: entry `sub` holds (non-empty) + (max differs from min) + third hashes; exclusive scan over the table
     const int per = nS / BT, i0 = tid * per;                           // nS >= BT
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void bk_gather_kernel(const uint32_t *__restri
 __global__ void bk_pair_flag_kernel(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ read, int64_t n, int32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    flag[i] = (i == 0 || hash[i] != hash[i - 1] || read[i] != read[i - 1]) ? 1 : 0;
+    flag[i] = (i == 0 || hash[i] != hash[i - 1] || ((read[i] ^ read[i - 1]) & 0x7FFFFFFFu)) ? 1 : 0;   // bit 31: multi-tile mark, not part of the id
 }
 __global__ void bk_set_dcount_kernel(uint32_t *dcount, int b, const unsigned long long *n) { dcount[b] = (uint32_t)*n; }
 
@@ -311,12 +328,12 @@ int finish_segment(dg_ctx *c, SketchState &S, int b, size_t s, size_t n) {
     uint32_t *r1 = S.d_aux.as<uint32_t>(), *r2 = r1 + n;
     uint64_t *h1 = S.d_hash.as<uint64_t>(), *h2 = S.d_uniq.as<uint64_t>();
     size_t tb = 0, tb2 = 0, tb3 = 0;
-    DG_HIP(rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t *)br, r1, (const uint64_t *)bh, h1, n, 0, 32, st));
+    DG_HIP(rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t *)br, r1, (const uint64_t *)bh, h1, n, 0, 31, st));
     DG_HIP(rocprim::radix_sort_pairs(nullptr, tb2, (const uint64_t *)h1, h2, (const uint32_t *)r1, r2, n, 0, 64, st));
     DG_HIP(rocprim::reduce_by_key(nullptr, tb3, h2, S.d_flag.as<int32_t>(), n, bh, (int32_t *)br, S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(),
                                   rocprim::equal_to<uint64_t>(), st));
     if (int rc = S.d_tmp.ensure(std::max(tb, std::max(tb2, tb3)))) return rc;
-    DG_HIP(rocprim::radix_sort_pairs(S.d_tmp.p, tb, (const uint32_t *)br, r1, (const uint64_t *)bh, h1, n, 0, 32, st));
+    DG_HIP(rocprim::radix_sort_pairs(S.d_tmp.p, tb, (const uint32_t *)br, r1, (const uint64_t *)bh, h1, n, 0, 31, st));
     DG_HIP(rocprim::radix_sort_pairs(S.d_tmp.p, tb2, (const uint64_t *)h1, h2, (const uint32_t *)r1, r2, n, 0, 64, st));
     hipLaunchKernelGGL(bk_pair_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h2, r2, (int64_t)n, S.d_flag.as<int32_t>());
     DG_HIP(rocprim::reduce_by_key(S.d_tmp.p, tb3, h2, S.d_flag.as<int32_t>(), n, bh, (int32_t *)br, S.d_n.as<unsigned long long>(), rocprim::plus<int32_t>(),
@@ -343,10 +360,10 @@ int common_buffers(dg_ctx *c, SketchState &S, const BucketPlan &plan) {
 
 }  // namespace
 
-void bucket_plan(const SketchState &S, int64_t n_reads, int64_t nt, int64_t n_win, int w, BucketPlan *plan) {
+void bucket_plan(const SketchState &S, int64_t n_reads, int64_t nt, int64_t n_win, int64_t n_multi, int w, BucketPlan *plan) {
     *plan = BucketPlan{};
+    plan->has_multi = n_multi > 0;
     if (S.opt_mode == 1 || nt <= 0 || n_win >= ((int64_t)1 << 31) || n_reads >= ((int64_t)1 << 31)) return;
-    if (nt > n_reads + n_reads / 8) return;                            // mostly reads of several tiles: their pairs all go through the residual list
     // ~2.5 k pairs per bucket at the emission density of random sequence (2 / (w + 1) per window)
     const int64_t n_est = std::max<int64_t>(nt, 2 * n_win / (w + 1));
     int bbits = S.opt_bucket_bits > 0 ? S.opt_bucket_bits : bits_for((uint64_t)((n_est + 2559) / 2560 - 1));
@@ -404,7 +421,7 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
     *outcome = 0;
     if (!fast) DG_HIP(hipMemsetAsync(ovf, 0, 8, s));
     hipLaunchKernelGGL(bk_table_kernel, dim3(B), dim3(BT), table_lds_bytes(plan.sbits), s, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), bstart, fill, stride,
-                       plan.bbits, plan.sbits, plan.residual_cap, dcount, ovf);
+                       plan.bbits, plan.sbits, plan.residual_cap, plan.has_multi ? 1 : 0, dcount, ovf);
     hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, S.d_bk_status.as<int64_t>());
     if (out_hash)                                                      // caller's buffers: gather before the status is known (repeated if the host had to finish buckets)
         hipLaunchKernelGGL(bk_gather_kernel, dim3(B), dim3(256), 0, s, bstart, stride, dcount, dstart, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), out_hash, out_cnt, cap);
@@ -415,7 +432,7 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
     if (S.h_status[3]) { *outcome = 1; return DG_OK; }                 // a bucket ran over its stride (pairs were dropped)
     const int64_t n_ovf = S.h_status[2];
     S.stat_overflow = n_ovf;
-    if (n_ovf > OVF_MAX) { *outcome = 2; return DG_OK; }
+    if (n_ovf > (S.opt_host_buckets > 0 ? std::min(S.opt_host_buckets, OVF_MAX) : OVF_MAX)) { *outcome = 2; return DG_OK; }
     if (n_ovf > 0) {
         std::vector<uint32_t> list((size_t)n_ovf), tab((size_t)B + 1);
         DG_HIP(hipMemcpyAsync(list.data(), ovf + 2, 4 * (size_t)n_ovf, hipMemcpyDeviceToHost, s));

@@ -157,8 +157,9 @@ int dg_sketch_get_timing(dg_ctx *, dg_sketch_timing *);
  *                          all (hash, read) pairs + reduce-by-key.  The output is the same bit for bit.
  *   bucket_bits b          0 (default): buckets sized to the input; 1..15: 2^b buckets
  *   bucket_stride n        0 (default): 12288 slots per bucket in mode 0
- *   residual_cap n         0 (default): 1024 residual entries per bucket (third hashes of a table entry, pairs of reads of
- *                          several tiles); fewer (-1: none) leave more buckets to the host's per-segment finish
+ *   residual_cap n         0 (default): 1024 residual entries per bucket (third hashes of a table entry); fewer (-1: none)
+ *                          leave more buckets to the host's per-segment finish
+ *   host_buckets n         0 (default): up to 256 buckets may be left to the host before the generic path takes over; 1..256
  * dg_sketch_get_stat names, about the last dg_sketch_reads / dg_sketch_reads_dev call: spectrum_path (0 buckets filled by the
  * tile kernel, 1 exact placement, 2 generic), buckets, overflow_buckets (finished by the host per segment) */
 int dg_sketch_set_option(dg_ctx *, const char *name, int64_t value);

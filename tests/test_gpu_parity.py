@@ -71,7 +71,7 @@ SPECTRUM_MODES = {          # name: (options, spectrum_path expected: 0 tile ker
     "stride_overrun": ({"bucket_bits": 4, "bucket_stride": 512}, 1),                 # a bucket runs over its stride: repeated with exact placement
     "host_segments": ({"bucket_bits": 3, "bucket_stride": 1 << 17, "residual_cap": 1}, 0),                       # residual lists overflow: those buckets are finished per segment with rocPRIM
     "host_segments_exact": ({"spectrum_mode": 2, "bucket_bits": 3, "residual_cap": 1}, 1),
-    "no_residual": ({"bucket_bits": 9, "residual_cap": -1}, 2),                      # > 256 buckets would need the host: the generic sort after all
+    "too_many_host_segments": ({"bucket_bits": 3, "bucket_stride": 1 << 17, "residual_cap": 1, "host_buckets": 2}, 2),   # more buckets need the host than allowed: the generic sort after all
 }
 
 
@@ -82,13 +82,13 @@ def _spectrum_reads(rng):
     x, y = _rnd(rng, 500), _rnd(rng, 700)
     reads += [x + y + x, x + x + x + y, y + synth.revcomp(y)]                                 # the same hash in several tiles of one read
     reads += [x[:60] + x[:60] + x[:40], y[:75] + synth.revcomp(y[:75])]                       # ... and twice in one tile
-    reads += [genome[s:s + 300] for s in rng.integers(0, len(genome) - 300, 300)]             # two-tile reads: their pairs go through the residual lists
+    reads += [genome[s:s + 300] for s in rng.integers(0, len(genome) - 300, 300)]             # two-tile reads: the same (hash, read) may come from both tiles
     reads += [reads[5]] * 700 + [b"", b"ACGT", _rnd(rng, 300, b"ACGTN"), b"A" * 400, b"AC" * 200]
     return reads
 
 
 def _reset_spectrum_options(ctx):
-    for key in ("spectrum_mode", "bucket_bits", "bucket_stride", "residual_cap"):
+    for key in ("spectrum_mode", "bucket_bits", "bucket_stride", "residual_cap", "host_buckets"):
         ctx.sketch_set_option(key, 0)
 
 
@@ -137,14 +137,26 @@ def test_sketch_spectrum_heavy_hitters(gpu_ctx):
     assert dict(zip(hg.tolist(), cg.tolist())) == want
 
 
-def test_sketch_spectrum_long_reads_take_the_generic_sort(gpu_ctx):
-    """read sets made of reads longer than one tile (128 windows) are left to the generic path: every pair of theirs would go
-    through the residual lists"""
+@pytest.mark.parametrize("mode", ["buckets", "exact_placement", "host_segments"])
+def test_sketch_spectrum_multi_tile_reads(gpu_ctx, mode):
+    """read sets made of reads longer than one tile (128 windows): the same (hash, read) can be emitted by several tiles; the
+    bucket's hash set keeps one of each (repeats inside a read are frequent here: every read carries a duplicated segment)"""
     rng = np.random.default_rng(9)
-    reads = [_rnd(rng, 400) for _ in range(500)]
-    hg, cg = gpu_ctx.sketch_reads(reads, 21, 11)
-    assert gpu_ctx.sketch_stat("spectrum_path") == 2
+    genome = _rnd(rng, 20000)
+    reads = []
+    for s0 in rng.integers(0, len(genome) - 400, 1500):
+        r = genome[s0:s0 + 400]
+        reads.append(r + r[40:240] + synth.revcomp(r[100:300]))
+    reads += [_rnd(rng, 150) for _ in range(300)] + [reads[0]] * 50
     ho, co = orc.sketch_reads(reads, 21, 11)
+    opts, want_path = SPECTRUM_MODES[mode]
+    try:
+        for key, v in opts.items():
+            gpu_ctx.sketch_set_option(key, v)
+        hg, cg = gpu_ctx.sketch_reads(reads, 21, 11)
+        assert gpu_ctx.sketch_stat("spectrum_path") == want_path
+    finally:
+        _reset_spectrum_options(gpu_ctx)
     assert np.array_equal(hg, ho) and np.array_equal(cg, co)
 
 

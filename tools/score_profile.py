@@ -14,6 +14,8 @@ gfa, _, _ = synth.ensure_mhc24(cache)
 arr = np.load(synth.ensure_mhc24_reads(cache), mmap_mode="r")
 n = int(sys.argv[1]) if len(sys.argv) > 1 and int(sys.argv[1]) > 0 else arr.shape[0]
 arr = np.array(arr[:n]); rl = arr.shape[1]
+if "pairs" in sys.argv[2:]:                                  # 300-bp reads (two tiles each): pairs of reads joined
+    arr = arr[: n // 2 * 2].reshape(-1, 2 * rl); n, rl = arr.shape
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0)
 if "exact" in sys.argv[2:]: ctx.sketch_set_option("spectrum_mode", 2)
