@@ -163,8 +163,8 @@ struct DpState {
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
     int64_t l2_prefetch = 6;                            // l2_prefetch: levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
-    int64_t use_lean_chain = 1;                         // lean_chain: the lean chain walk where the lattice allows it (0: always the general one); next load
-    bool lean_chain = false;
+    int64_t use_lean_chain = 1;                         // lean_chain: 1 the lean walk where the lattice allows it, 0 always the general one, 2 the two-ahead walk (second row records; measured slower, kept for parity runs); next load
+    bool lean_chain = false, pair_chain = false;
     // single-window score deltas computed beside the sweep: piece k (transitions of levels >= delta_piece_level[k]) signals delta_piece_ev[k]
     std::vector<hipEvent_t> delta_piece_ev;
     std::vector<int32_t> delta_piece_level;
@@ -206,7 +206,7 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t n_grp = 0, n_dead = 0, n_heavy_rows = 0, n_slot_records = 0, n_rowx_words = 0, n_dtrans = 0, n_edges = 0;   // logical table sizes (dg_dp_get_table_digest)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
-    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl, d_chainlv, d_rowdone, d_chainprobe;
+    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowrec2, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl, d_chainlv, d_rowdone, d_chainprobe;
 #ifdef DG_SWEEP_PROBE
     DevBuf d_probe;
 #endif
@@ -285,5 +285,6 @@ void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s);
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s);
 void trace_launch_finish(const DpState &S, hipStream_t s);
 void trace_debug_report(const DpState &S);
+int trace_build_second_records(DpState &S, hipStream_t s);   // rowrec2 of the pair walk, from the row records on the device
 
 }  // namespace dgi

@@ -559,6 +559,10 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         max_k = B.max_k;
         lap("table uploads");
     }
+    // the two-ahead walk of the traceback (option lean_chain = 2) wants a second record per vertex (16 B); beyond 2 GB of them the lean walk does
+    S.pair_chain = S.lean_chain && S.use_lean_chain >= 2 && (size_t)nV * 16 <= ((size_t)2 << 30);
+    if (S.pair_chain) { if (int rc = trace_build_second_records(S, s)) return rc; }
+    else S.d_rowrec2.release();
     S.n_dtrans = (int64_t)dtrans.size();
     S.n_edges = g->out_off[nV];
     plan_delta_windows(S, dtrans, dblk_first);

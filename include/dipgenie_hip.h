@@ -98,7 +98,7 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   digest 0|1            accumulate the per-level digests
  *   fast 0|1              0: generic sweep kernel only          adaptive_rc 0|1   0: one chunk of all r per task
  *   coop 0|1|2            cooperative fan-in rows off / by cost model / whenever possible
- *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1    lean chain walk where the lattice allows it (next load)
+ *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1|2  1: lean chain walk where the lattice allows it, 0: the general one, 2: the two-ahead walk (second row records; slower, parity runs) (next load)
  *   graph_batch n         levels per hipGraph batch (-1: default 1000, 0: plain launches)
  *   l2_prefetch n         levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
  *   pf_far n              levels ahead at which the prefetcher's far blocks pull tables into the Infinity Cache (0: periodic launches instead)

@@ -260,12 +260,12 @@ def test_dp_device_tables_equal_host_tables(gpu_ctx):
         gpu_ctx.dp_set_option("host_tables", 0)
 
 
-@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch", "host_tables"])
+@pytest.mark.parametrize("mode", ["generic", "no_adaptive", "no_coop", "force_coop", "no_rowx", "general_chain", "two_ahead_walk", "no_l2_prefetch", "no_delta_overlap", "forced_delta_overlap", "no_far_prefetch", "host_tables"])
 def test_dp_alternative_kernels(gpu_ctx, mode):
     """the generic fallback sweep, the fixed-RC launch, cooperative rows off / forced, the path without row in-edge
     matrices and the general chain walk (in place of the lean one) must all give the oracle's answer"""
     opts = {"generic": {"fast": 0}, "no_adaptive": {"adaptive_rc": 0}, "no_coop": {"coop": 0}, "force_coop": {"coop": 2}, "no_rowx": {"rowx": 0},
-            "general_chain": {"lean_chain": 0}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}, "host_tables": {"host_tables": 1}}[mode]
+            "general_chain": {"lean_chain": 0}, "two_ahead_walk": {"lean_chain": 2}, "no_l2_prefetch": {"l2_prefetch": 0}, "no_delta_overlap": {"delta_overlap": 0}, "forced_delta_overlap": {"delta_overlap": 2}, "no_far_prefetch": {"pf_far": 0}, "host_tables": {"host_tables": 1}}[mode]
     try:
         for k, v in opts.items():
             gpu_ctx.dp_set_option(k, v)
@@ -284,7 +284,7 @@ def test_dp_alternative_kernels(gpu_ctx, mode):
             gpu_ctx.dp_set_option(k, v)
 
 
-@pytest.mark.parametrize("lean", [1, 0])
+@pytest.mark.parametrize("lean", [2, 1, 0])
 def test_dp_corrupt_lattice_is_an_error_not_a_fault(gpu_ctx, lean):
     """a damaged back-pointer lattice (one level overwritten between sweep and walk) must end in DG_ERR_STATE from both chain
     walks -- never in a wild colour-list read of the finish kernel: 0xFF = the "unreachable" word, 0x01 = rank 1 everywhere
