@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         }
         if (MODE == 3 && emit) {
             const uint32_t b = (uint32_t)(H >> (64 - be.bbits));
-            const uint32_t pos = atomicAdd(&be.fill[b], 1u);
+            const uint32_t pos = atomicAdd(&be.fill[(size_t)b * FILL_PAD], 1u);   // one counter per 64-byte line: atomics on one line serialise at the memory side
             if (pos < be.stride) {
                 const size_t at = (size_t)b * be.stride + pos;
                 be.bk_hash[at] = H;

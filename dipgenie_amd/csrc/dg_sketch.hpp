@@ -4,6 +4,7 @@
 
 namespace dgi {
 
+constexpr int FILL_PAD = 16;            // words between two buckets' fill counters (a 64-byte line each)
 // where the tile kernel puts a read minimizer in bucket form: bucket = top bbits of the hash, slot = fill[bucket]++ (< stride)
 struct BucketEmit { uint32_t *fill = nullptr; uint64_t *bk_hash = nullptr; uint32_t *bk_read = nullptr; int bbits = 1; uint32_t stride = 0; };
 struct BucketPlan { bool ok = false, has_multi = false; int bbits = 0, sbits = 0, B = 0, G = 0; uint32_t stride = 0, residual_cap = 0; };

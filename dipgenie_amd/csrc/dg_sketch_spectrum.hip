@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     uint32_t *scr = (uint32_t *)(rfl + RCAP);                          // [0..16] scan, [20] residual count, [21] hash-set entries
     size_t s;
     uint32_t n;
-    if (stride) { s = (size_t)b * stride; n = fill[b]; if (n > stride) { if (tid == 0) { dcount[b] = 0; atomicAdd(&ovf[1], 1u); } return; } }
+    if (stride) { s = (size_t)b * stride; n = fill[(size_t)b * FILL_PAD]; if (n > stride) { if (tid == 0) { dcount[b] = 0; atomicAdd(&ovf[1], 1u); } return; } }
     else { s = start[b]; n = start[b + 1] - start[b]; }
     if (n == 0) { if (tid == 0) dcount[b] = 0; return; }
     const int lowbits = 64 - bbits - sbits;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BT) void bk_dscan_kernel(const uint32_t *__restrict
     const int per = (B + BT - 1) / BT, i0 = threadIdx.x * per;
     uint32_t sum = 0;
     unsigned long long np = 0;
-    for (int i = i0; i < min(B, i0 + per); ++i) { sum += dcount[i]; if (fill) np += fill[i]; }
+    for (int i = i0; i < min(B, i0 + per); ++i) { sum += dcount[i]; if (fill) np += fill[(size_t)i * FILL_PAD]; }
     uint32_t total, run = block_excl_scan(sum, scr, &total);
     for (int i = i0; i < min(B, i0 + per); ++i) { const uint32_t v = dcount[i]; dstart[i] = run; run += v; }
     if (fill && np) atomicAdd(&pairs, np);
@@ -381,8 +381,8 @@ int bucket_fast_begin(dg_ctx *c, SketchState &S, const BucketPlan &plan, BucketE
     const size_t slots = (size_t)plan.B * plan.stride;
     if (int rc = S.d_bk_hash.ensure(8 * slots)) return rc;
     if (int rc = S.d_bk_read.ensure(4 * slots)) return rc;
-    if (int rc = S.d_bk_fill.ensure(4 * (size_t)(plan.B + OVF_MAX + 16))) return rc;     // fill counters | the table kernel's overflow record
-    DG_HIP(hipMemsetAsync(S.d_bk_fill.p, 0, 4 * (size_t)(plan.B + 16), c->stream));        // the one memset of the pass (a multiple of 64 bytes: one fill kernel)
+    if (int rc = S.d_bk_fill.ensure(4 * ((size_t)plan.B * FILL_PAD + OVF_MAX + 16))) return rc;   // fill counters (a line each) | the table kernel's overflow record
+    DG_HIP(hipMemsetAsync(S.d_bk_fill.p, 0, 4 * ((size_t)plan.B * FILL_PAD + 16), c->stream));     // the one memset of the pass
     *be = BucketEmit{S.d_bk_fill.as<uint32_t>(), S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), plan.bbits, plan.stride};
     return DG_OK;
 }
@@ -417,7 +417,7 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
     const uint32_t stride = fast ? plan.stride : 0;
     const uint32_t *bstart = fast ? nullptr : S.d_bk_start.as<uint32_t>(), *fill = fast ? S.d_bk_fill.as<uint32_t>() : nullptr;
     uint32_t *dcount = S.d_bk_dcount.as<uint32_t>(), *dstart = S.d_bk_dstart.as<uint32_t>();
-    uint32_t *ovf = fast ? S.d_bk_fill.as<uint32_t>() + B : S.d_bk_ovf.as<uint32_t>();
+    uint32_t *ovf = fast ? S.d_bk_fill.as<uint32_t>() + (size_t)B * FILL_PAD : S.d_bk_ovf.as<uint32_t>();
     *outcome = 0;
     if (!fast) DG_HIP(hipMemsetAsync(ovf, 0, 8, s));
     hipLaunchKernelGGL(bk_table_kernel, dim3(B), dim3(BT), table_lds_bytes(plan.sbits), s, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), bstart, fill, stride,
@@ -434,12 +434,12 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
     S.stat_overflow = n_ovf;
     if (n_ovf > (S.opt_host_buckets > 0 ? std::min(S.opt_host_buckets, OVF_MAX) : OVF_MAX)) { *outcome = 2; return DG_OK; }
     if (n_ovf > 0) {
-        std::vector<uint32_t> list((size_t)n_ovf), tab((size_t)B + 1);
+        std::vector<uint32_t> list((size_t)n_ovf), tab(fast ? (size_t)B * FILL_PAD : (size_t)B + 1);
         DG_HIP(hipMemcpyAsync(list.data(), ovf + 2, 4 * (size_t)n_ovf, hipMemcpyDeviceToHost, s));
-        DG_HIP(hipMemcpyAsync(tab.data(), fast ? fill : bstart, 4 * (size_t)(fast ? B : B + 1), hipMemcpyDeviceToHost, s));
+        DG_HIP(hipMemcpyAsync(tab.data(), fast ? fill : bstart, 4 * tab.size(), hipMemcpyDeviceToHost, s));
         DG_HIP(hipStreamSynchronize(s));
         for (uint32_t b : list) {
-            const size_t at = fast ? (size_t)b * stride : (size_t)tab[b], n = fast ? tab[b] : tab[b + 1] - tab[b];
+            const size_t at = fast ? (size_t)b * stride : (size_t)tab[b], n = fast ? tab[(size_t)b * FILL_PAD] : tab[b + 1] - tab[b];
             if (int rc = finish_segment(c, S, (int)b, at, n)) return rc;
         }
         hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, S.d_bk_status.as<int64_t>());

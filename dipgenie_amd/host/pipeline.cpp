@@ -238,11 +238,13 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
             if (!(h < inj_hap.size() && inj_hap[h].set)) { in.hap.reserve(tot); for (size_t i = 0; i < ns; ++i) in.hap += node_seq[paths[h][i]]; }
             return in;
         };
-        std::future<HapInput> next;
-        if (num_walks > 0) next = std::async(std::launch::async, assemble, 0u);
+        // (several helpers: one assembly takes longer than the device needs for a haplotype -- 6 ms against 2 on MHC-24)
+        const uint32_t depth = (uint32_t)std::max(1, std::min(opt.threads - 1, 6));
+        std::vector<std::future<HapInput>> ahead(depth);
+        for (uint32_t q = 0; q < depth && q < num_walks; ++q) ahead[q] = std::async(std::launch::async, assemble, q);
         for (uint32_t h = 0; h < num_walks; ++h) {
-            HapInput cur = next.get();
-            if (h + 1 < num_walks) next = std::async(std::launch::async, assemble, h + 1);
+            HapInput cur = ahead[h % depth].get();
+            if (h + depth < num_walks) ahead[h % depth] = std::async(std::launch::async, assemble, h + depth);
             const std::string &hap = cur.hap;
             const std::vector<int64_t> &seg_start = cur.seg_start;
             const std::vector<int32_t> &step_vtx = cur.step_vtx;
