@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
-    const bool active = tile_id < n_tiles;              // inactive waves only take part in the barriers
+    const bool active = tile_id < n_tiles;              // inactive waves (the grid's last workgroup) only take part in the two barriers around the hashing
     Tile T{0, 0, 0, 0, 0};
     if (active) T = tiles[tile_id];
     const int has_prev = T.win0 > 0 ? 1 : 0;
@@ -203,26 +203,39 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     uint8_t *sq = info + (TW + w);                                     // [TW + w + k]
 
     const char *src = bases + T.seq_start + km0;
-    for (int t = lane; t < nb; t += 64) sq[t] = upper((uint8_t)src[t]);
-    __syncthreads();
-
-    // canonical 2-bit code / orientation per k-mer (first base most significant: integer order ==
-    // lexicographic order; A<C<G<T matches ASCII).  The bases are turned into three bit planes with wave ballots (low
-    // code bit, high code bit, "not ACGT"), so a k-mer's forward and reverse-complement codes are two bit-field
-    // extractions + an interleave instead of a k-step loop over LDS bytes.
+    // Staging, four bases per lane: one dword load, then SWAR -- upper-casing, 2-bit codes (A<C<G<T as in ASCII), "not ACGT" flags.
+    // The four codes packed to a byte are OR-ed into the 32-base word of the 2-bit stream they belong to, the flags (a nibble) into the
+    // invalid plane: one LDS atomic each.  (Before: a byte load, an LDS round trip and three ballots per base, and a 60-instruction bit
+    // interleave per 32-base word -- a third of the kernel's instructions.)
     uint64_t *plane = (uint64_t *)(base + PLANE_OFF(k, w));           // [3][PLANE_WORDS]: (unused), (unused), not-ACGT
     uint64_t *stream = (uint64_t *)(base + STREAM_OFF(k, w));         // [2 * PLANE_WORDS + 1]: 2-bit codes, base t at bits [2t, 2t + 1]
     if (lane < 3 * PLANE_WORDS) plane[lane] = 0;
     if (lane < 2 * PLANE_WORDS + 1) stream[lane] = 0;
-    __syncthreads();
-    for (int rd = 0; rd * 64 < nb; ++rd) {
-        const int t = rd * 64 + lane;
-        const int cf = t < nb ? code2(sq[t]) : -1;
-        const unsigned long long mlo = __ballot(cf >= 0 && (cf & 1)), mhi = __ballot(cf >= 0 && (cf & 2)), minv = __ballot(t < nb && cf < 0);
-        if (lane == 0) { plane[2 * PLANE_WORDS + rd] = minv; stream[2 * rd] = spread32(mlo) | (spread32(mhi) << 1); }
-        if (lane == 1) stream[2 * rd + 1] = spread32(mlo >> 32) | (spread32(mhi >> 32) << 1);
+    WAVE_SYNC();                                                       // (the four waves of a workgroup work on tiles of their own: wave-level ordering is all the staging needs)
+    {
+        uint32_t *stream32 = (uint32_t *)stream, *inv32 = (uint32_t *)(plane + 2 * PLANE_WORDS);
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // bit 7 of every non-zero byte
+        for (int t0 = 4 * lane; t0 < nb; t0 += 256) {
+            uint32_t b = 0;
+            if (t0 + 4 <= nb) b = ((const U32 *)(src + t0))->v;
+            else for (int q = 0; t0 + q < nb; ++q) b |= (uint32_t)(uint8_t)src[t0 + q] << (8 * q);
+            const uint32_t x7 = b & 0x7F7F7F7Fu;
+            const uint32_t lower = (x7 + 0x1F1F1F1Fu) & ~(x7 + 0x05050505u) & ~b & 0x80808080u;    // 'a' + 0x1F = 0x80 = 'z' + 1 + 0x05
+            const uint32_t u = b - (lower >> 2);
+            for (int q = 0; q < 4 && t0 + q < nb; ++q) sq[t0 + q] = (uint8_t)(u >> (8 * q));
+            const uint32_t bad = (nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u)) >> 7;   // 1 per byte that is not A, C, G, T
+            const uint32_t x = (u >> 1) & 0x03030303u;                 // A 0, C 1, T 2, G 3
+            const uint32_t code = (x ^ ((x >> 1) & 0x01010101u)) & ~(bad * 3u);
+            const uint32_t pack8 = ((code * 0x01041040u) >> 24) & 0xFFu, inv4 = ((bad * 0x01020408u) >> 24) & 0xFu;
+            atomicOr(&stream32[t0 >> 4], pack8 << ((t0 & 15) << 1));
+            if (inv4) atomicOr(&inv32[t0 >> 5], inv4 << (t0 & 31));
+        }
     }
-    __syncthreads();
+    WAVE_SYNC();
+#ifdef DG_TILE_DEBUG
+    if (((bucket_mode >> 8) & 15) == 2) return;
+#endif
     bool lane_inv = false;
     for (int q = lane; q < nkm; q += 64) {
         bool valid = (k <= 32) && bits_at(plane + 2 * PLANE_WORDS, q, k) == 0;
@@ -243,7 +256,10 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         }
         info[q] = (uint8_t)((valid ? 1 : 0) | (o << 1));
     }
-    __syncthreads();
+    WAVE_SYNC();
+#ifdef DG_TILE_DEBUG
+    if (((bucket_mode >> 8) & 15) == 3) return;
+#endif
 
     // window minima (ties -> newest, solver.cpp:316)
     const int nw_all = active ? T.nwin + has_prev : 0;
@@ -301,8 +317,10 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             wpos[wi] = best;
         }
     }
-    __syncthreads();
-    if (!active) return;
+    WAVE_SYNC();
+#ifdef DG_TILE_DEBUG
+    if (((bucket_mode >> 8) & 15) == 4) return;
+#endif
 
     // emission (solver.cpp:329-335 / 401-407): a minimizer is emitted where its hash differs from the previous window's.
     // Windows sharing their argmin form runs; every run's k-mer is hashed ONCE (one lane per run), then run j is emitted iff
@@ -318,23 +336,43 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
         if (head) run_w[n_runs + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint16_t)wi;
         n_runs += __popcll(m);
     }
-    WAVE_SYNC();
-    for (int j0 = 0; j0 < n_runs; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < n_runs) {
-            const int p = wpos[run_w[j]];
-            const int op = (info[p] >> 1) & 1;
-            const bool vp = info[p] & 1;
-            const uint64_t cp = code[p];
-            if (vp) {
-                run_h[j] = murmur3_code(cp, k);                        // pure ACGT: the key's words come straight from the code
-            } else {
-                auto bp = [&](int t) -> uint8_t { return canon_byte(sq, p, k, op, t); };
-                run_h[j] = murmur3_fold(bp, k);
+    // Hashing is the costliest phase per instruction (~300 for MurmurHash3 of one k-mer) and the emptiest: a 150-bp read has ~8 runs,
+    // 8 lanes of 64.  The kernel is bound by its instruction count, so the runs of the workgroup's four tiles are hashed TOGETHER by
+    // one wave (their records are in LDS already; ~32 lanes busy, the code runs once instead of four times).
+    int *hdr = (int *)(smem + 4 * (size_t)lds_per_wave);               // runs per wave
+    if (lane == 0) hdr[wave] = n_runs;
+    __syncthreads();
+    if (wave == (int)(blockIdx.x & 3)) {                               // (rotating: a workgroup's wave i sits on SIMD i -- always wave 0 would load one SIMD of four)
+        const int p1 = hdr[0], p2 = p1 + hdr[1], p3 = p2 + hdr[2], tot = p3 + hdr[3];
+        for (int g0 = 0; g0 < tot; g0 += 64) {
+            const int g = g0 + lane;
+            if (g < tot) {
+                const int v = (g >= p1 ? 1 : 0) + (g >= p2 ? 1 : 0) + (g >= p3 ? 1 : 0);
+                const int j = g - (v == 0 ? 0 : (v == 1 ? p1 : (v == 2 ? p2 : p3)));
+                unsigned char *bv = smem + (size_t)v * lds_per_wave;
+                const uint64_t *code_v = (const uint64_t *)bv;
+                const int32_t *wpos_v = (const int32_t *)(code_v + (TW + w));
+                const uint8_t *info_v = (const uint8_t *)(wpos_v + (TW + 1)), *sq_v = info_v + (TW + w);
+                uint64_t *mc_v = (uint64_t *)(bv + TABLE_OFF(k, w));
+                const uint16_t *mp_v = (const uint16_t *)(mc_v + (TW + w) + (TW + 1));
+                const int p = wpos_v[mp_v[j]];
+                const int op = (info_v[p] >> 1) & 1;
+                const bool vp = info_v[p] & 1;
+                const uint64_t cp = code_v[p];
+                if (vp) {
+                    mc_v[j] = murmur3_code(cp, k);                     // pure ACGT: the key's words come straight from the code
+                } else {
+                    auto bp = [&](int t) -> uint8_t { return canon_byte(sq_v, p, k, op, t); };
+                    mc_v[j] = murmur3_fold(bp, k);
+                }
             }
         }
     }
-    WAVE_SYNC();
+    __syncthreads();
+    if (!active) return;
+#ifdef DG_TILE_DEBUG
+    if (((bucket_mode >> 8) & 15) == 5) return;
+#endif
     int64_t wbase = (MODE == 1 || MODE == 2) ? tile_base[tile_id] : 0;
     int64_t total = 0;
     const bool multi_tile = (int64_t)T.seq_len - k - w + 2 > TW;
@@ -520,6 +558,11 @@ __global__ void dict_count_rank_kernel(const uint64_t *__restrict__ dict, int64_
 }
 
 // ------------------------------------------------------------------ host side
+#ifdef DG_TILE_DEBUG                     // measurement build (tools/tile_phases.sh): the tile kernel returns after phase $DG_TILE_DEBUG
+#define DG_TILE_DEBUG_BITS (getenv("DG_TILE_DEBUG") ? atoi(getenv("DG_TILE_DEBUG")) << 8 : 0)
+#else
+#define DG_TILE_DEBUG_BITS 0
+#endif
 static SketchState &state(dg_ctx *c) {
     if (!c->sk) c->sk = new SketchState();
     return *c->sk;
@@ -571,7 +614,7 @@ static int launch_tiles_sparse(dg_ctx *c, const char *bases_dev, int64_t nt, int
     if (int rc = S.d_hash2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;     // sparse output (dead before the sort reuses them)
     if (int rc = S.d_aux2.ensure(8 * (size_t)std::max<int64_t>(n_win, 1))) return rc;
     const size_t lpw = lds_per_wave(k, w);
-    hipLaunchKernelGGL((sketch_tile_kernel<2, AUX_IS_POS>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+    hipLaunchKernelGGL((sketch_tile_kernel<2, AUX_IS_POS>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw + 16, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
                        S.d_tile_cnt.as<int64_t>(), S.d_tile_sparse.as<int64_t>(), S.d_hash2.as<uint64_t>(), S.d_aux2.as<int64_t>(), (int)lpw, bucket_mode, BucketEmit{});
     DG_HIP(hipGetLastError());
     return DG_OK;
@@ -582,8 +625,8 @@ static int launch_tiles_buckets(dg_ctx *c, const char *bases_dev, int64_t nt, in
     SketchState &S = state(c);
     if (nt == 0) return DG_OK;
     const size_t lpw = lds_per_wave(k, w);
-    hipLaunchKernelGGL((sketch_tile_kernel<3, false>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
-                       (int64_t *)nullptr, (const int64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr, (int)lpw, 1, be);
+    hipLaunchKernelGGL((sketch_tile_kernel<3, false>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 4 * lpw + 16, c->stream, bases_dev, S.d_tiles.as<Tile>(), nt, k, w,
+                       (int64_t *)nullptr, (const int64_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr, (int)lpw, 1 | DG_TILE_DEBUG_BITS, be);
     DG_HIP(hipGetLastError());
     return DG_OK;
 }
