@@ -267,7 +267,49 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     uint64_t *ac = mc + (TW + w);                                      // [TW + 1]
     uint16_t *mp = (uint16_t *)(ac + (TW + 1));                        // [TW + w]
     uint16_t *ap = mp + (TW + w);                                      // [TW + 1]
-    if (__ballot(lane_inv) == 0) {
+    if (__ballot(lane_inv) == 0 && nkm <= 128) {
+        // every k-mer pure ACGT and at most two per lane (a 150-bp read): the doubling below with the table in REGISTERS -- lane l
+        // keeps k-mers l and l + 64, an entry's partner h places up comes through ds_bpermute.  No LDS table, no wave syncs: the LDS
+        // form was the largest phase of the kernel (0.50 of 1.47 ms on the config-4 reads).
+        uint64_t c0 = lane < nkm ? code[lane] : 0, c1 = lane + 64 < nkm ? code[lane + 64] : 0;
+        uint32_t p0 = (uint32_t)lane, p1 = (uint32_t)lane + 64u;
+        uint64_t a0 = 0, a1 = 0;                                        // window minima: windows l and l + 64
+        uint32_t q0 = 0, q1 = 0;
+        auto fetch = [&](int dist, uint64_t &fc0, uint32_t &fp0, uint64_t &fc1, uint32_t &fp1, int &row_of0) {
+            // entries (lane + dist) of the table as seen from row 0 (fc0 / fp0) and from row 1 (fc1 / fp1: row 1 only, else invalid)
+            const int sl = ((lane + dist) & 63) << 2;
+            const uint32_t x0l = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)(uint32_t)c0), x0h = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)(uint32_t)(c0 >> 32));
+            const uint32_t x1l = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)(uint32_t)c1), x1h = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)(uint32_t)(c1 >> 32));
+            const uint32_t y0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)p0), y1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)p1);
+            row_of0 = (lane + dist) >> 6;                               // 0: the partner of a row-0 entry is in row 0, 1: in row 1, 2: beyond
+            const bool r1 = row_of0 == 1;
+            fc0 = r1 ? ((uint64_t)x1h << 32 | x1l) : ((uint64_t)x0h << 32 | x0l); fp0 = r1 ? y1 : y0;
+            fc1 = (uint64_t)x1h << 32 | x1l; fp1 = y1;
+        };
+        int off = 0;
+        bool first = true;
+        for (int L = 1; L <= w; L <<= 1) {
+            if (L > 1) {
+                const int h = L >> 1;
+                uint64_t fc0, fc1; uint32_t fp0, fp1; int ro;
+                fetch(h, fc0, fp0, fc1, fp1, ro);
+                const bool ok0 = lane + h < nkm && ro < 2, ok1 = ro == 0 && lane + 64 + h < nkm;
+                if (ok0 && fc0 <= c0) { c0 = fc0; p0 = fp0; }
+                if (ok1 && fc1 <= c1) { c1 = fc1; p1 = fp1; }
+            }
+            if (w & L) {
+                uint64_t fc0 = c0, fc1 = c1; uint32_t fp0 = p0, fp1 = p1; int ro = 0;
+                if (off) fetch(off, fc0, fp0, fc1, fp1, ro);
+                // (windows exist only where all their k-mers do: wi + off < nkm for every wi < nw_all)
+                if (lane < nw_all && (first || fc0 <= a0)) { a0 = fc0; q0 = fp0; }
+                if (lane + 64 < nw_all && (first || fc1 <= a1)) { a1 = fc1; q1 = fp1; }
+                off += L;
+                first = false;
+            }
+        }
+        if (lane < nw_all) wpos[lane] = (int32_t)q0;
+        if (lane + 64 < nw_all) wpos[lane + 64] = (int32_t)q1;
+    } else if (__ballot(lane_inv) == 0) {
         // every k-mer of the tile is pure ACGT: minima by doubling.  m_L[q] = (smallest code, its newest position) over
         // k-mers [q, q + L), built in place for L = 1, 2, 4, ... (m_2L[q] = m_L[q] (+) m_L[q + L], "later wins on <="); a
         // window of w k-mers is the concatenation of one range per set bit of w, lowest bit first.  ~8 LDS round trips per
