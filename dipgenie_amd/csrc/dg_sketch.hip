@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     if (lane < 3 * PLANE_WORDS) plane[lane] = 0;
     if (lane < 2 * PLANE_WORDS + 1) stream[lane] = 0;
     WAVE_SYNC();                                                       // (the four waves of a workgroup work on tiles of their own: wave-level ordering is all the staging needs)
+    bool tile_inv = false;
     {
         uint32_t *stream32 = (uint32_t *)stream, *inv32 = (uint32_t *)(plane + 2 * PLANE_WORDS);
         struct __attribute__((packed)) U32 { uint32_t v; };
@@ -230,15 +231,17 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             const uint32_t pack8 = ((code * 0x01041040u) >> 24) & 0xFFu, inv4 = ((bad * 0x01020408u) >> 24) & 0xFu;
             atomicOr(&stream32[t0 >> 4], pack8 << ((t0 & 15) << 1));
             if (inv4) atomicOr(&inv32[t0 >> 5], inv4 << (t0 & 31));
+            tile_inv |= inv4 != 0;
         }
     }
+    const bool any_inv = __ballot(tile_inv) != 0;                      // (most tiles are pure ACGT: their k-mers skip the look at the invalid plane)
     WAVE_SYNC();
 #ifdef DG_TILE_DEBUG
     if (((bucket_mode >> 8) & 15) == 2) return;
 #endif
     bool lane_inv = false;
     for (int q = lane; q < nkm; q += 64) {
-        bool valid = (k <= 32) && bits_at(plane + 2 * PLANE_WORDS, q, k) == 0;
+        bool valid = (k <= 32) && (!any_inv || bits_at(plane + 2 * PLANE_WORDS, q, k) == 0);
         lane_inv |= !valid;
         int o;
         if (valid) {
