@@ -8,13 +8,16 @@
 // emitted when its hash differs from the previous window's; hash = h1^h2 of MurmurHash3_x64_128 over
 // the k ASCII bytes, seed 0 (restated from the published algorithm).
 //
-// Kernel shape: one wave (64 lanes) per tile of <=128 windows, 4 tiles per 256-thread workgroup.
-// The tile's bases are staged once in LDS; every lane builds 2-bit codes for its k-mers (valid for
-// pure-ACGT k-mers, k<=32, where 2-bit order == ASCII order), scans its windows, and hashes only
-// window minima whose position changed. K-mers containing other bytes fall to an in-kernel bytewise
-// comparison -- same result, no host fallback. Emission is two-pass (count, scan, write) so output
-// order is deterministic; the per-read set semantics and the global spectrum come from one stable
-// radix sort by hash + a (hash,read) run flag + reduce_by_key (rocPRIM primitives).
+// Kernel shape: one wave (64 lanes) per tile of <=128 windows, 4 tiles per 256-thread workgroup.  The kernel is bound by its
+// instruction count (one wave per 150-bp read), so every phase is written for few wave instructions: bases are staged four per
+// lane (dword load, SWAR upper-casing / 2-bit codes / not-ACGT flags, OR-ed into a 2-bit stream and an invalid plane in LDS);
+// every lane builds the canonical 2-bit codes of its k-mers (pure ACGT, k<=32, where 2-bit order == ASCII order) from the
+// stream; window minima by doubling, in registers for tiles of <=128 k-mers; only window minima whose position changed are
+// hashed, the workgroup's four tiles together by one wave.  K-mers containing other bytes fall to an in-kernel bytewise
+// comparison -- same result, no host fallback.  Reads: every minimizer goes straight into the bucket of its hash range and the
+// spectrum (Sp_R: distinct hashes, reads per hash) comes from one LDS table per bucket (dg_sketch_spectrum.hip); the generic
+// route (sparse output, compaction, stable radix sort by hash + (hash,read) run flags + reduce_by_key, rocPRIM) is kept.
+// Haplotypes: sparse output + compaction, order = sequence order.
 #include <cstring>
 #include <string.h>
 
