@@ -140,8 +140,68 @@ int Pipeline::load_reads(std::string &err) {                           // solver
 // ======================================================================================
 int Pipeline::compute_and_classify_anchors(std::string &err) {
     const int k = opt.k;
-    // ---- haplotype sketches (index_kmers, solver.cpp:277-363) ----
+    // Order of the stages: the reference sketches the haplotypes first, then the reads, then joins, then fits (solver.cpp:449-887).
+    // Nothing in the haplotype index depends on the reads and the fit needs only the reads' multiplicity histogram, so the reads are
+    // sketched FIRST and the fit (0.15 s of host arithmetic on MHC-24) runs on its thread beside the haplotype index and the anchor
+    // join instead of in front of the graph stage.  The log lines keep the reference's order.
     double t0 = now_s();
+    // ---- read sketches: Read_hashes / Sp_R / kmer_count (solver.cpp:526-555, 711-732) ----
+    std::vector<uint64_t> sp_hash;     // sorted distinct read-minimizer hashes; id = rank (:541-546)
+    std::vector<int32_t> sp_count;     // number of reads containing it (== kmer_count)
+    if (spectrum_injected) {                                           // the read-sharded ranks' merged spectrum (dist_sketch.py)
+        for (size_t q = 1; q < inj_sp_hash.size(); ++q)
+            if (inj_sp_hash[q] <= inj_sp_hash[q - 1]) { err = "injected spectrum: hashes must be strictly ascending"; return -1; }
+        if (inj_sp_count.size() != inj_sp_hash.size()) { err = "injected spectrum: one count per hash"; return -1; }
+        sp_hash = inj_sp_hash; sp_count = inj_sp_count;
+    } else {
+        std::vector<int64_t> off(reads.size() + 1, 0);
+        for (size_t r = 0; r < reads.size(); ++r) off[r + 1] = off[r] + (int64_t)reads[r].second.size();
+        std::string bases;
+        bases.reserve((size_t)off.back());
+        for (auto &rd : reads) bases += rd.second;
+        uint64_t *hh = nullptr; int32_t *cc = nullptr; int64_t n = 0;
+        int rc = be.sketch_reads(be.ctx, bases.data(), off.data(), (int64_t)reads.size(), k, opt.w, &hh, &cc, &n);
+        if (rc != 0) { err = std::string("sketch_reads failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
+        sp_hash.assign(hh, hh + n);
+        sp_count.assign(cc, cc + n);
+        be.free_buf(hh); be.free_buf(cc);
+    }
+    count_sp_r = (int32_t)sp_hash.size();
+    sum.spectrum = count_sp_r;
+    stamp("compute_hashes+Sp_R", t0);
+    // ---- multiplicity histogram, fit, classify (:745-879) ----
+    std::map<int32_t, int32_t> kmer_freq;                              // :745-750
+    for (int32_t c : sp_count) kmer_freq[c] += 1;
+    if (spectrum_injected && !inj_hist.empty()) {                      // the ranks' all-reduced Hist_kmer must be the histogram of the counts they sent
+        std::vector<int64_t> mine(inj_hist.size(), 0);
+        for (auto &kv : kmer_freq) mine[std::min<size_t>((size_t)std::max(kv.first, 0), mine.size() - 1)] += kv.second;
+        if (mine != inj_hist) { err = "injected multiplicity histogram does not match the injected counts"; return -1; }
+    }
+    std::vector<HistBin> hist;
+    int max_mult = 0;
+    for (auto &kv : kmer_freq) { hist.push_back({(int)kv.first, (double)kv.second}); max_mult = std::max(max_mult, (int)kv.first); }
+    // The grid fit (serial in the reference, :785) needs nothing but the histogram, and nothing before the colour split of the
+    // graph stage needs its result (homo_bv): it runs on a thread of its own beside the first phases of that stage
+    // (wait_fit() joins it and prints its two lines).
+    auto job = [this, hist, max_mult, threads = std::max(1, opt.threads / 2)]() {
+        sum.fit = kg_fit(hist, /*max_copy=*/10, max_mult, threads);
+        const KGParams &P = sum.fit.P;
+        std::vector<int8_t> label(max_mult + 1, -1);
+        homo_bv.assign(count_sp_r, 0);                                 // :830-879
+        fit_n_hom = 0;
+        for (int32_t id = 0; id < count_sp_r; ++id) {
+            int m = fit_sp_count[id];
+            if (m == 0) continue;
+            if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
+            homo_bv[id] = (uint8_t)label[m];
+            fit_n_hom += label[m];
+        }
+    };
+    fit_sp_count.swap(sp_count);
+    fit_pending = true;
+    if (opt.threads > 1 && !getenv("DG_FIT_INLINE")) fit_thread = std::thread(job); else job();
+    // ---- haplotype sketches (index_kmers, solver.cpp:277-363) ----
+    t0 = now_s();
     struct HapIndex { std::vector<uint64_t> hash; std::vector<uint32_t> voff; std::vector<int32_t> v; };
     std::vector<HapIndex> kmer_index(num_walks);
     sum.minimizers_per_hap.assign(num_walks, 0);
@@ -274,32 +334,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     if (getenv("DG_DEBUG")) fprintf(stderr, "[dg::index] backend sketch calls %.3f s of %.3f s\n", t_sketch, now_s() - t0);
     stamp("index_kmers", t0);
 
-    // ---- read sketches: Read_hashes / Sp_R / kmer_count (solver.cpp:526-555, 711-732) ----
-    t0 = now_s();
-    std::vector<uint64_t> sp_hash;     // sorted distinct read-minimizer hashes; id = rank (:541-546)
-    std::vector<int32_t> sp_count;     // number of reads containing it (== kmer_count)
-    if (spectrum_injected) {                                           // the read-sharded ranks' merged spectrum (dist_sketch.py)
-        for (size_t q = 1; q < inj_sp_hash.size(); ++q)
-            if (inj_sp_hash[q] <= inj_sp_hash[q - 1]) { err = "injected spectrum: hashes must be strictly ascending"; return -1; }
-        if (inj_sp_count.size() != inj_sp_hash.size()) { err = "injected spectrum: one count per hash"; return -1; }
-        sp_hash = inj_sp_hash; sp_count = inj_sp_count;
-    } else {
-        std::vector<int64_t> off(reads.size() + 1, 0);
-        for (size_t r = 0; r < reads.size(); ++r) off[r + 1] = off[r] + (int64_t)reads[r].second.size();
-        std::string bases;
-        bases.reserve((size_t)off.back());
-        for (auto &rd : reads) bases += rd.second;
-        uint64_t *hh = nullptr; int32_t *cc = nullptr; int64_t n = 0;
-        int rc = be.sketch_reads(be.ctx, bases.data(), off.data(), (int64_t)reads.size(), k, opt.w, &hh, &cc, &n);
-        if (rc != 0) { err = std::string("sketch_reads failed: ") + (be.last_error ? be.last_error() : "?"); return -1; }
-        sp_hash.assign(hh, hh + n);
-        sp_count.assign(cc, cc + n);
-        be.free_buf(hh); be.free_buf(cc);
-    }
-    count_sp_r = (int32_t)sp_hash.size();
-    sum.spectrum = count_sp_r;
     if (!opt.quiet) fprintf(stderr, "[M::%s] Indexed reads with spectrum size: %d\n", __func__, count_sp_r);   // :558
-    stamp("compute_hashes+Sp_R", t0);
 
     // ---- compute_anchors (solver.cpp:415-446, 560-575): hap minimizers whose hash is in Sp_R ----
     t0 = now_s();
@@ -541,45 +576,13 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
     }
     stamp("compute_anchors+filter+sort", t0);
 
-    // ---- multiplicity histogram, fit, classify (:745-879) ----
-    t0 = now_s();
-    std::map<int32_t, int32_t> kmer_freq;                              // :745-750
-    for (int32_t c : sp_count) kmer_freq[c] += 1;
-    if (spectrum_injected && !inj_hist.empty()) {                      // the ranks' all-reduced Hist_kmer must be the histogram of the counts they sent
-        std::vector<int64_t> mine(inj_hist.size(), 0);
-        for (auto &kv : kmer_freq) mine[std::min<size_t>((size_t)std::max(kv.first, 0), mine.size() - 1)] += kv.second;
-        if (mine != inj_hist) { err = "injected multiplicity histogram does not match the injected counts"; return -1; }
-    }
-    std::vector<HistBin> hist;
-    int max_mult = 0;
-    for (auto &kv : kmer_freq) { hist.push_back({(int)kv.first, (double)kv.second}); max_mult = std::max(max_mult, (int)kv.first); }
     if (!opt.quiet) std::cout << "Classifying kmers..." << std::endl;  // :784
-    // The grid fit (serial in the reference, :785) needs nothing but the histogram, and nothing before the colour split of the
-    // graph stage needs its result (homo_bv): it runs on a thread of its own beside the first phases of that stage
-    // (wait_fit() joins it and prints its two lines).
-    fit_t0 = t0;
-    auto job = [this, hist, max_mult, threads = std::max(1, opt.threads / 2)]() {
-        sum.fit = kg_fit(hist, /*max_copy=*/10, max_mult, threads);
-        const KGParams &P = sum.fit.P;
-        std::vector<int8_t> label(max_mult + 1, -1);
-        homo_bv.assign(count_sp_r, 0);                                 // :830-879
-        fit_n_hom = 0;
-        for (int32_t id = 0; id < count_sp_r; ++id) {
-            int m = fit_sp_count[id];
-            if (m == 0) continue;
-            if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
-            homo_bv[id] = (uint8_t)label[m];
-            fit_n_hom += label[m];
-        }
-    };
-    fit_sp_count.swap(sp_count);
-    fit_pending = true;
-    if (opt.threads > 1 && !getenv("DG_FIT_INLINE")) fit_thread = std::thread(job); else job();
     return 0;
 }
 
 void Pipeline::wait_fit() {                                             // homo_bv is valid after this
     if (!fit_pending) return;
+    fit_t0 = now_s();                                                  // the stage's time is what the caller waits here
     if (fit_thread.joinable()) fit_thread.join();
     fit_pending = false;
     const KGParams &P = sum.fit.P;
