@@ -139,7 +139,45 @@ void parse_L(Builder &b, std::vector<char *> &f) {          // gfa-io.cpp:279-36
 // so "known when this line was read" is exactly id < n_seg_then.
 struct PendingWalk { std::string line; uint32_t n_seg_then; };
 
-void parse_W(const Builder &b, PendingWalk &pw, GfaWalk &t, std::string &warnings) {
+// Segment names -> ids for the walk steps (10^8 lookups on a chr22-scale panel): open addressing over the entries of name2id, looked
+// up by (pointer, length) -- no std::string per step, no node chasing.  Read-only; built once when the S lines are in.
+struct NameIndex {
+    std::vector<const std::pair<const std::string, uint32_t> *> slot, by_id;   // by_id: a walk mostly steps to one of the next few segments of the file
+    uint64_t mask = 0;
+    static uint64_t hash(const char *p, size_t n) {
+        uint64_t h = 0xcbf29ce484222325ULL;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 0x100000001b3ULL; }
+        return h ^ (h >> 29);
+    }
+    explicit NameIndex(const std::unordered_map<std::string, uint32_t> &m) {
+        size_t cap = 16;
+        while (cap < 2 * m.size() + 2) cap <<= 1;
+        slot.assign(cap, nullptr);
+        mask = cap - 1;
+        by_id.assign(m.size(), nullptr);
+        for (const auto &kv : m) {
+            uint64_t q = hash(kv.first.data(), kv.first.size()) & mask;
+            while (slot[q]) q = (q + 1) & mask;
+            slot[q] = &kv;
+            if (kv.second < by_id.size()) by_id[kv.second] = &kv;
+        }
+    }
+    // the same answer as find(), tried first on the ids right after `last` (sequential memory instead of two cache misses per step)
+    const uint32_t *find_near(uint32_t last, const char *p, size_t n) const {
+        for (uint32_t c = last + 1; c < last + 5 && c < by_id.size(); ++c) {
+            const auto *e = by_id[c];
+            if (e && e->first.size() == n && memcmp(e->first.data(), p, n) == 0) return &e->second;
+        }
+        return find(p, n);
+    }
+    const uint32_t *find(const char *p, size_t n) const {
+        for (uint64_t q = hash(p, n) & mask; slot[q]; q = (q + 1) & mask)
+            if (slot[q]->first.size() == n && memcmp(slot[q]->first.data(), p, n) == 0) return &slot[q]->second;
+        return nullptr;
+    }
+};
+
+void parse_W(const Builder &b, const NameIndex &names, PendingWalk &pw, GfaWalk &t, std::string &warnings) {
     std::vector<char *> f;
     split_tabs(pw.line, f);
     if (f.size() < 7) return;
@@ -148,13 +186,14 @@ void parse_W(const Builder &b, PendingWalk &pw, GfaWalk &t, std::string &warning
     const char *q = f[6];
     const char *end = q + strlen(q);
     const char *qq = q;
-    std::string name;
+    (void)b;
+    uint32_t last = 0xFFFFFFFFu;                                        // (+ 1 = 0: the first step tries the file's first segments)
     for (const char *pp = q + 1; pp <= end; ++pp) {
         if (pp == end || *pp == '>' || *pp == '<') {
-            name.assign(qq + 1, pp - (qq + 1));
-            auto it = b.name2id.find(name);
-            if (it != b.name2id.end() && it->second < pw.n_seg_then) t.v.push_back(it->second << 1 | (uint32_t)(*qq == '<'));
-            else warnings += "WARNING: failed to find segment '" + name + "'\n";
+            const uint32_t *id = names.find_near(last, qq + 1, (size_t)(pp - (qq + 1)));
+            if (id) last = *id;
+            if (id && *id < pw.n_seg_then) t.v.push_back(*id << 1 | (uint32_t)(*qq == '<'));
+            else warnings += "WARNING: failed to find segment '" + std::string(qq + 1, pp - (qq + 1)) + "'\n";
             qq = pp;
         }
     }
@@ -265,8 +304,9 @@ bool read_gfa_file(const std::string &path, GfaGraph &g, std::string &err) {
     {
         g.walks.resize(pending.size());
         std::vector<std::string> warn(pending.size());
+        const NameIndex names(b.name2id);
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t w = 0; w < (int64_t)pending.size(); ++w) parse_W(b, pending[w], g.walks[w], warn[w]);
+        for (int64_t w = 0; w < (int64_t)pending.size(); ++w) parse_W(b, names, pending[w], g.walks[w], warn[w]);
         for (auto &ws : warn) if (!ws.empty()) fputs(ws.c_str(), stderr);
     }
     lap("parse W lines");
