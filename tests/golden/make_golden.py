@@ -104,6 +104,27 @@ def run_ref(gfa, reads, args, threads=4):
     return d
 
 
+def gfa_variants(cases):
+    """bub_a with its lines rearranged, for the GFA reader's corners: S lines in shuffled order (segment ids, assigned by first
+    appearance, no longer follow the names), a walk step naming a segment that does not exist (warning, step dropped), an S line
+    that comes after the first W line (that walk's steps on it are dropped, gfa-io.cpp)."""
+    import random
+    ed = os.path.join(HERE, "e2e")
+    src = open(os.path.join(ed, "bub_a.gfa")).read().split("\n")
+    S = [l for l in src if l.startswith("S\t")]; L = [l for l in src if l.startswith("L\t")]
+    W = [l for l in src if l.startswith("W\t")]; H = [l for l in src if l.startswith("H")]
+    rnd = random.Random(3)
+    S2 = S[:]; rnd.shuffle(S2)
+    w0 = W[0].split("\t"); w0[6] = w0[6].replace(">5", ">5>nosuch", 1) if ">5" in w0[6] else w0[6] + ">nosuch"
+    open(os.path.join(ed, "gfa_shuffled.gfa"), "w").write("\n".join(H + S2 + L + ["\t".join(w0)] + W[1:]) + "\n")
+    open(os.path.join(ed, "gfa_late_segment.gfa"), "w").write("\n".join(H + S[:-1] + L + [W[0]] + [S[-1]] + W[1:]) + "\n")
+    for name, base, args in (("gfa_shuffled", "gfa_shuffled", ["-p2", "-R3"]), ("gfa_shuffled_p1", "gfa_shuffled", ["-p1", "-R3"]),
+                             ("gfa_late_segment", "gfa_late_segment", ["-p2", "-R3"]), ("gfa_late_segment_p1", "gfa_late_segment", ["-p1", "-R3"])):
+        cases[name] = dict(gfa=f"tests/golden/e2e/{base}.gfa", reads="tests/golden/e2e/bub_a.fa",
+                           **run_ref(os.path.join(ed, base + ".gfa"), os.path.join(ed, "bub_a.fa"), args))
+        print(name, cases[name].get("dp_value"), cases[name]["fasta_md5"], flush=True)
+
+
 def e2e():
     cases = {}
     D = os.path.join(ROOT, "tests", "data")
@@ -143,6 +164,7 @@ def e2e():
             synth.write_fasta(reads, rd)
         cases[name] = dict(gfa=f"tests/golden/e2e/{base}.gfa", reads=f"tests/golden/e2e/{base}.fa", **run_ref(gfa, reads, args))
         print(name, cases[name].get("dp_value"), cases[name].get("r1"), cases[name].get("r2"), cases[name]["fasta_md5"], flush=True)
+    gfa_variants(cases)
     # MHC_4 (reference's own test data), values from reference runs in this container (-t1 and -t8 identical)
     cases["mhc4_p2"] = dict(gfa="tests/data/MHC_4.gfa.gz", reads="tests/data/CHM13_reads.fq.gz", args=["-p2", "-R18"],
                             fasta_md5="46394489af8bc9026605ddf237aca4c7", dp_value=60729, r1=17, r2=1, len1=5005629, len2=4920284,
