@@ -387,10 +387,16 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
     // Hashing is the costliest phase per instruction (~300 for MurmurHash3 of one k-mer) and the emptiest: a 150-bp read has ~8 runs,
     // 8 lanes of 64.  The kernel is bound by its instruction count, so the runs of the workgroup's four tiles are hashed TOGETHER by
     // one wave (their records are in LDS already; ~32 lanes busy, the code runs once instead of four times).
-    int *hdr = (int *)(smem + 4 * (size_t)lds_per_wave);               // runs per wave
-    if (lane == 0) hdr[wave] = n_runs;
+    int *hdr = (int *)(smem + 4 * (size_t)lds_per_wave);               // [0..3] runs per wave; [4..7] read id | multi-tile << 31; [8..11] has_prev
+    if (lane == 0) {
+        hdr[wave] = n_runs;
+        hdr[4 + wave] = (int)((uint32_t)T.seq_id | ((int64_t)T.seq_len - k - w + 2 > TW ? 1u << 31 : 0u));
+        hdr[8 + wave] = has_prev;
+    }
     __syncthreads();
-    if (wave == (int)(blockIdx.x & 3)) {                               // (rotating: a workgroup's wave i sits on SIMD i -- always wave 0 would load one SIMD of four)
+    const bool hasher = wave == (int)(blockIdx.x & 3);                 // (rotating: a workgroup's wave i sits on SIMD i -- always wave 0 would load one SIMD of four)
+    if (MODE == 3 && !hasher) return;                                  // bucket form: the hashing wave also emits for the whole workgroup (below)
+    if (hasher) {
         const int p1 = hdr[0], p2 = p1 + hdr[1], p3 = p2 + hdr[2], tot = p3 + hdr[3];
         for (int g0 = 0; g0 < tot; g0 += 64) {
             const int g = g0 + lane;
@@ -414,6 +420,35 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
                     mc_v[j] = murmur3_fold(bp, k);
                 }
             }
+        }
+        if (MODE == 3) {
+            // ... and the emission of all four tiles: one pass of the emission code per workgroup instead of four (it was a fifth of
+            // the kernel), the returning atomics of ~32 minimizers in one instruction.  Same rules as below: run j of a tile is
+            // emitted iff its hash differs from run j - 1's (context run 0 of a continuing tile: never) and from every earlier run's.
+            WAVE_SYNC();
+            for (int g0 = 0; g0 < tot; g0 += 64) {
+                const int g = g0 + lane;
+                if (g < tot) {
+                    const int v = (g >= p1 ? 1 : 0) + (g >= p2 ? 1 : 0) + (g >= p3 ? 1 : 0);
+                    const int j = g - (v == 0 ? 0 : (v == 1 ? p1 : (v == 2 ? p2 : p3)));
+                    const uint64_t *mc_v = (const uint64_t *)(smem + (size_t)v * lds_per_wave + TABLE_OFF(k, w));
+                    const int hp = hdr[8 + v];
+                    const uint64_t H = mc_v[j];
+                    bool emit = j >= hp && H != (j == 0 ? UINT64_MAX : mc_v[j - 1]);
+                    if (emit)                                          // (a first hash equal to the initial prev_hash is never emitted: it shadows nothing, solver.cpp:329)
+                        for (int a = (!hp && mc_v[0] == UINT64_MAX) ? 1 : 0; a < j - 1; ++a) if (mc_v[a] == H) { emit = false; break; }
+                    if (emit) {
+                        const uint32_t b = (uint32_t)(H >> (64 - be.bbits));
+                        const uint32_t pos = atomicAdd(&be.fill[(size_t)b * FILL_PAD], 1u);   // one counter per 64-byte line: atomics on one line serialise at the memory side
+                        if (pos < be.stride) {
+                            const size_t at = (size_t)b * be.stride + pos;
+                            be.bk_hash[at] = H;
+                            be.bk_read[at] = (uint32_t)hdr[4 + v];
+                        }
+                    }
+                }
+            }
+            return;
         }
     }
     __syncthreads();
@@ -455,15 +490,6 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
             const int64_t slot = wbase + total + __popcll(m & ((1ULL << lane) - 1ULL));
             out_hash[slot] = H;
             out_aux[slot] = AUX_IS_POS ? (int64_t)(km0 + p) : ((int64_t)T.seq_id | ((bucket_mode && multi_tile) ? (int64_t)1 << 31 : 0));
-        }
-        if (MODE == 3 && emit) {
-            const uint32_t b = (uint32_t)(H >> (64 - be.bbits));
-            const uint32_t pos = atomicAdd(&be.fill[(size_t)b * FILL_PAD], 1u);   // one counter per 64-byte line: atomics on one line serialise at the memory side
-            if (pos < be.stride) {
-                const size_t at = (size_t)b * be.stride + pos;
-                be.bk_hash[at] = H;
-                be.bk_read[at] = (uint32_t)T.seq_id | (multi_tile ? 1u << 31 : 0u);
-            }
         }
         total += __popcll(m);
     }
