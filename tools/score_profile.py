@@ -18,6 +18,8 @@ if "pairs" in sys.argv[2:]:                                  # 300-bp reads (two
     arr = arr[: n // 2 * 2].reshape(-1, 2 * rl); n, rl = arr.shape
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0)
+for a in sys.argv[2:]:
+    if "=" in a: ctx.sketch_set_option(a.split("=")[0], int(a.split("=")[1]))      # e.g. bucket_bits=11
 if "exact" in sys.argv[2:]: ctx.sketch_set_option("spectrum_mode", 2)
 if "generic" in sys.argv[2:]: ctx.sketch_set_option("spectrum_mode", 1)
 _, seqs, _, walks = synth.parse_gfa(gfa)
