@@ -900,11 +900,11 @@ void sweep_launch_chain(DpState &S, SweepLaunch &X, int l0, int M, hipStream_t s
     int *abort_flag = &S.d_pfctl.as<PfCtl>()->chain_abort;
     S.launch_hist[63 * 4 + 3]++;
     S.levels_chained += M;
-#define DG_CHAIN(RCV, DG) hipLaunchKernelGGL((dp_sweep_chain_kernel<RCV, DG>), dim3(run), dim3(256), 0, s, lv, D, X.F, rowdone, abort_flag, S.d_descs.as<LevelDesc>(), S.d_heavy.as<int32_t>())
-#define DG_CHAIN_RC(DG) do { switch (rc) { case 1: DG_CHAIN(1, DG); break; case 2: DG_CHAIN(2, DG); break; case 3: DG_CHAIN(3, DG); break; default: DG_CHAIN(4, DG); break; } } while (0)
+#define DG_CHAIN_LAUNCH(RCV, DG) hipLaunchKernelGGL((dp_sweep_chain_kernel<RCV, DG>), dim3(run), dim3(256), 0, s, lv, D, X.F, rowdone, abort_flag, S.d_descs.as<LevelDesc>(), S.d_heavy.as<int32_t>())
+#define DG_CHAIN_RC(DG) do { switch (rc) { case 1: DG_CHAIN_LAUNCH(1, DG); break; case 2: DG_CHAIN_LAUNCH(2, DG); break; case 3: DG_CHAIN_LAUNCH(3, DG); break; default: DG_CHAIN_LAUNCH(4, DG); break; } } while (0)
     if (S.want_digest) DG_CHAIN_RC(true); else DG_CHAIN_RC(false);
 #undef DG_CHAIN_RC
-#undef DG_CHAIN
+#undef DG_CHAIN_LAUNCH
 }
 
 #else   // the product library is built without the chained dispatches (measured 3-6x slower): `make chain` builds them
