@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
             for (uint32_t probe = 0; probe < cap; ++probe) {
                 const uint32_t old = atomicCAS(&set[slot], EMPTY, i);
                 if (old == EMPTY) { bk_read[s + i] = r & 0x7FFFFFFFu; atomicAdd(&scr[21], 1u); break; }
-                if (bk_hash[s + old] == h && ((bk_read[s + old] ^ r) & 0x7FFFFFFFu) == 0) break;
+                if (bk_hash[s + old] == h && ((bk_read[s + old] ^ r) & 0x7FFFFFFFu) == 0) break;   // (its owner may be clearing bit 31 right now: masked, so either value compares the same)
                 slot = (slot + 1) & (cap - 1);
             }
         }
