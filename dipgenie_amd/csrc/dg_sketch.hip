@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void sketch_tile_kernel(const char *__restrict
                             const size_t at = (size_t)b * be.stride + pos;
                             be.bk_hash[at] = H;
                             be.bk_read[at] = (uint32_t)hdr[4 + v];
+                        } else {                                       // the bucket is full (a hash held by > ~10 k reads): the shared spill list
+                            const uint32_t sp = atomicAdd(be.spill_n, 1u);
+                            if (sp < be.spill_cap) { be.spill_hash[sp] = H; be.spill_read[sp] = (uint32_t)hdr[4 + v]; }
                         }
                     }
                 }
@@ -892,6 +895,7 @@ extern "C" int dg_sketch_set_option(dg_ctx *c, const char *name, int64_t value) 
     else if (n == "bucket_bits") { if (value < 0 || value > 15) { set_error("bucket_bits must be 0 (automatic) .. 15"); return DG_ERR_ARG; } S.opt_bucket_bits = (int)value; }
     else if (n == "bucket_stride") { if (value < 0 || value > (1 << 20)) { set_error("bucket_stride out of range"); return DG_ERR_ARG; } S.opt_stride = (int)value; S.sticky_exact = false; }
     else if (n == "host_buckets") { if (value < 0 || value > 256) { set_error("host_buckets must be 0 (default 256) .. 256"); return DG_ERR_ARG; } S.opt_host_buckets = (int)value; }
+    else if (n == "spill_cap") { if (value < -1 || value > ((int64_t)1 << 28)) { set_error("spill_cap must be -1 (none) .. 2^28, 0 = default"); return DG_ERR_ARG; } S.opt_spill_cap = value; S.sticky_exact = false; }
     else if (n == "residual_cap") { if (value < -1 || value > 1024) { set_error("residual_cap must be -1 (none) .. 1024, 0 = default"); return DG_ERR_ARG; } S.opt_residual_cap = (int)value; }
     else { set_error("dg_sketch_set_option: unknown option '%s'", name); return DG_ERR_ARG; }
     return DG_OK;
@@ -904,6 +908,7 @@ extern "C" int dg_sketch_get_stat(dg_ctx *c, const char *name, int64_t *value) {
     if (n == "spectrum_path") *value = S.stat_path;                    // 0 buckets filled by the tile kernel, 1 buckets placed from the sparse output, 2 generic sort
     else if (n == "buckets") *value = S.stat_buckets;
     else if (n == "overflow_buckets") *value = S.stat_overflow;
+    else if (n == "spilled_pairs") *value = S.stat_spilled;
     else { set_error("dg_sketch_get_stat: unknown name '%s'", name); return DG_ERR_ARG; }
     return DG_OK;
 }

@@ -6,19 +6,22 @@ namespace dgi {
 
 constexpr int FILL_PAD = 16;            // words between two buckets' fill counters (a 64-byte line each)
 // where the tile kernel puts a read minimizer in bucket form: bucket = top bbits of the hash, slot = fill[bucket]++ (< stride)
-struct BucketEmit { uint32_t *fill = nullptr; uint64_t *bk_hash = nullptr; uint32_t *bk_read = nullptr; int bbits = 1; uint32_t stride = 0; };
-struct BucketPlan { bool ok = false, has_multi = false; int bbits = 0, sbits = 0, B = 0, G = 0; uint32_t stride = 0, residual_cap = 0; };
+// (a bucket that is full spills into one shared list: slot = (*spill_n)++ < spill_cap)
+struct BucketEmit { uint32_t *fill = nullptr; uint64_t *bk_hash = nullptr; uint32_t *bk_read = nullptr; int bbits = 1; uint32_t stride = 0;
+                    uint32_t *spill_n = nullptr; uint64_t *spill_hash = nullptr; uint32_t *spill_read = nullptr; uint32_t spill_cap = 0; };
+struct BucketPlan { bool ok = false, has_multi = false; int bbits = 0, sbits = 0, B = 0, G = 0; uint32_t stride = 0, residual_cap = 0, spill_cap = 0; };
 
 struct SketchState {
     DevBuf d_bases, d_off, d_seq_tiles, d_seq_wins, d_seq_tile0, d_seq_win0, d_tiles, d_tile_cnt, d_tile_base, d_tile_sparse, d_hash, d_aux, d_hash2, d_aux2, d_tmp, d_flag, d_uniq, d_cnt, d_n, d_kmers, d_out;
     // bucketed spectrum (dg_sketch_spectrum.hip): bucket arrays, the (workgroup x bucket) count matrix, per-bucket tables
-    DevBuf d_bk_hash, d_bk_read, d_matrix, d_bk_start, d_bk_fill, d_bk_dcount, d_bk_dstart, d_bk_ovf, d_bk_status;
+    DevBuf d_bk_hash, d_bk_read, d_matrix, d_bk_start, d_bk_fill, d_bk_dcount, d_bk_dstart, d_bk_ovf, d_bk_status, d_spill_hash, d_spill_read;
     bool attr_set = false;              // the kernels' dynamic-LDS limits are raised once per ctx
     bool sticky_exact = false;          // a bucket ran over its stride once: this ctx places buckets exactly from then on
     int64_t *h_status = nullptr;        // pinned: {pairs, distinct hashes, buckets left to the host, a bucket ran over its stride}
     // options (dg_sketch_set_option) and what the last dg_sketch_reads* call did (dg_sketch_get_stat)
     int opt_mode = 0, opt_bucket_bits = 0, opt_stride = 0, opt_residual_cap = 0, opt_host_buckets = 0;
-    int64_t stat_path = 0, stat_buckets = 0, stat_overflow = 0;
+    int64_t opt_spill_cap = 0;
+    int64_t stat_path = 0, stat_buckets = 0, stat_overflow = 0, stat_spilled = 0;
     dg_sketch_timing timing;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };

@@ -7,8 +7,9 @@
 //
 //   buckets   the top `bbits` bits of the hash choose one of B buckets (~2-3 k pairs each).  The tile kernel drops every
 //             minimizer straight into its bucket (slot = fill[bucket]++, B * stride slots; sketch_tile_kernel MODE 3), already
-//             free of repeats of a hash inside one tile.  If a bucket runs over its stride the pass is repeated with exact
-//             placement from the sparse tile output (hist -> scan -> basefill -> scatter below): any bucket size fits then.
+//             free of repeats of a hash inside one tile.  A full bucket (a hash held by > ~10 k reads) sends its further pairs to one
+//             shared spill list, which its table workgroup looks through; only if that list runs over too is the pass repeated with
+//             exact placement from the sparse tile output (hist -> scan -> basefill -> scatter below): any bucket size fits then.
 //   table     one workgroup per bucket.  The next `sbits` bits address a table in LDS with TWO hashes per entry, the
 //             smallest and the largest of the sub-bucket (64-bit LDS atomic min / max), and a count for each: B * 2^sbits
 //             entries for ~10^6 distinct hashes, so a third hash in an entry is rare (~1 % of the hashes).  Pairs are never
@@ -37,6 +38,7 @@ constexpr int STRIDE = 12288;           // slots per bucket when the tile kernel
 constexpr int RCAP = 1024;              // residual entries per bucket (one per lane)
 constexpr int SBITS_MIN = 12, SETCAP = 16384;   // hash-set slots of the multi-tile repeat filter at 2^12 table entries (64 of the tables' 112 KB)
 constexpr int SBITS = 12;               // table entries per bucket = 2^SBITS (112 KB of LDS: one workgroup per CU)
+constexpr int SPILL_CAP = 1 << 20;        // pairs the shared spill list of full buckets holds (12 MB)
 constexpr int OVF_MAX = 256;            // buckets finished by the host one by one; more -> generic path
 constexpr int G_MAX = 256;              // hist / scatter workgroups (one per CU)
 
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(BT) void bk_scatter_kernel(const int64_t *__restric
 struct Residual { uint64_t low; uint32_t sub, read; };
 __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_t *bk_read, const uint32_t *__restrict__ start,
                                                       const uint32_t *__restrict__ fill, uint32_t stride, int bbits, int sbits, uint32_t residual_cap,
-                                                      int has_multi, uint32_t *__restrict__ dcount, uint32_t *__restrict__ ovf) {
+                                                      int has_multi, uint32_t *__restrict__ dcount, uint32_t *__restrict__ ovf, const uint32_t *__restrict__ spill_n,
+                                                      const uint64_t *spill_hash, uint32_t *spill_read, uint32_t spill_cap) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int nS = 1 << sbits, tid = threadIdx.x, b = blockIdx.x;
     unsigned long long *mn = (unsigned long long *)lds_raw, *mx = mn + nS;
@@ -156,12 +159,33 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     uint8_t *rfl = (uint8_t *)(res + RCAP);
     uint32_t *scr = (uint32_t *)(rfl + RCAP);                          // [0..16] scan, [20] residual count, [21] hash-set entries
     size_t s;
-    uint32_t n;
-    if (stride) { s = (size_t)b * stride; n = fill[(size_t)b * FILL_PAD]; if (n > stride) { if (tid == 0) { dcount[b] = 0; atomicAdd(&ovf[1], 1u); } return; } }
-    else { s = start[b]; n = start[b + 1] - start[b]; }
+    uint32_t n, n_sp = 0;                                               // pairs in the bucket's own slots; entries of the spill list to look through
+    if (stride) {
+        s = (size_t)b * stride; n = fill[(size_t)b * FILL_PAD];
+        if (n > stride) {                                               // the rest of the bucket is in the shared spill list, among other buckets' pairs
+            n = stride; n_sp = spill_n[0];
+            if (n_sp > spill_cap) { if (tid == 0) { dcount[b] = 0; atomicAdd(&ovf[1], 1u); } return; }   // the list ran over too: exact placement
+        }
+    } else { s = start[b]; n = start[b + 1] - start[b]; }
     if (n == 0) { if (tid == 0) dcount[b] = 0; return; }
     const int lowbits = 64 - bbits - sbits;
     const unsigned long long lowmask = (1ULL << lowbits) - 1ULL;
+    const uint32_t n_all = n + n_sp;
+    // pair i of the bucket: its own slots first, then the spill list (entries of other buckets: false)
+    auto pair = [&](uint32_t i, unsigned long long &h, uint32_t &r) -> bool {
+        if (i < n) { h = bk_hash[s + i]; r = bk_read[s + i]; return true; }
+        h = spill_hash[i - n];
+        if ((uint32_t)(h >> (64 - bbits)) != (uint32_t)b) return false;
+        r = spill_read[i - n];
+        return true;
+    };
+    auto give_up = [&](bool to_host) {                                  // nothing of the bucket has been overwritten
+        if (tid == 0) {
+            dcount[b] = 0;
+            if (to_host && !n_sp) { const uint32_t o = atomicAdd(&ovf[0], 1u); if (o < OVF_MAX) ovf[2 + o] = (uint32_t)b; }   // the host finishes this segment
+            else atomicAdd(&ovf[1], 1u);                               // (a bucket with spilled pairs is not one segment: exact placement)
+        }
+    };
     if (has_multi) {
         // Pairs of reads longer than one tile (bit 31 of the read id): the same (hash, read) may have come from two tiles.  An
         // LDS hash set of pair indices keeps one of each and clears its bit; the repeats keep theirs and are skipped below.
@@ -171,40 +195,41 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
         for (uint32_t i = tid; i < cap; i += BT) set[i] = EMPTY;
         if (tid == 0) scr[21] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += BT) {
-            const uint32_t r = bk_read[s + i];
-            if (!(r >> 31)) continue;
-            const unsigned long long h = bk_hash[s + i];
+        for (uint32_t i = tid; i < n_all; i += BT) {
+            unsigned long long h; uint32_t r;
+            if (!pair(i, h, r) || !(r >> 31)) continue;
             unsigned long long m = (h ^ ((unsigned long long)(r & 0x7FFFFFFFu) * 0x9E3779B97F4A7C15ULL));
             m ^= m >> 29; m *= 0xBF58476D1CE4E5B9ULL; m ^= m >> 32;
             uint32_t slot = (uint32_t)m & (cap - 1);
             for (uint32_t probe = 0; probe < cap; ++probe) {
                 const uint32_t old = atomicCAS(&set[slot], EMPTY, i);
-                if (old == EMPTY) { bk_read[s + i] = r & 0x7FFFFFFFu; atomicAdd(&scr[21], 1u); break; }
-                if (bk_hash[s + old] == h && ((bk_read[s + old] ^ r) & 0x7FFFFFFFu) == 0) break;   // (its owner may be clearing bit 31 right now: masked, so either value compares the same)
+                if (old == EMPTY) { if (i < n) bk_read[s + i] = r & 0x7FFFFFFFu; else spill_read[i - n] = r & 0x7FFFFFFFu; atomicAdd(&scr[21], 1u); break; }
+                unsigned long long ho; uint32_t ro;
+                pair(old, ho, ro);                                      // (its owner may be clearing bit 31 right now: masked, so either value compares the same)
+                if (ho == h && ((ro ^ r) & 0x7FFFFFFFu) == 0) break;
                 slot = (slot + 1) & (cap - 1);
             }
         }
         __syncthreads();
-        if (scr[21] > cap / 2 + cap / 4) {                             // the set got too full to trust the probe bound: the host finishes the bucket
-            if (tid == 0) { dcount[b] = 0; const uint32_t o = atomicAdd(&ovf[0], 1u); if (o < OVF_MAX) ovf[2 + o] = (uint32_t)b; }
-            return;
-        }
+        if (scr[21] > cap / 2 + cap / 4) { give_up(true); return; }     // the set got too full to trust the probe bound
     }
     for (int i = tid; i < nS; i += BT) { mn[i] = ~0ULL; mx[i] = 0; cm[i] = 0; cM[i] = 0; nd[i] = 0; }
     if (tid == 0) scr[20] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += BT) {
-        const unsigned long long h = bk_hash[s + i], low = h & lowmask;
+    for (uint32_t i = tid; i < n_all; i += BT) {
+        unsigned long long h; uint32_t r;
+        if (!pair(i, h, r)) continue;
+        const unsigned long long low = h & lowmask;
         const uint32_t sub = (uint32_t)(h >> lowbits) & (uint32_t)(nS - 1);
         atomicMin(&mn[sub], low);
         atomicMax(&mx[sub], low);
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += BT) {
-        const unsigned long long h = bk_hash[s + i], low = h & lowmask;
-        const uint32_t sub = (uint32_t)(h >> lowbits) & (uint32_t)(nS - 1), r = bk_read[s + i];
-        if (r >> 31) continue;                                         // a repeat of a (hash, read) counted elsewhere
+    for (uint32_t i = tid; i < n_all; i += BT) {
+        unsigned long long h; uint32_t r;
+        if (!pair(i, h, r) || (r >> 31)) continue;                     // (bit 31 still set: a repeat of a (hash, read) counted elsewhere)
+        const unsigned long long low = h & lowmask;
+        const uint32_t sub = (uint32_t)(h >> lowbits) & (uint32_t)(nS - 1);
         if (low == mn[sub]) atomicAdd(&cm[sub], 1u);
         else if (low == mx[sub]) atomicAdd(&cM[sub], 1u);
         else {
@@ -214,10 +239,7 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     }
     __syncthreads();
     const uint32_t R = scr[20];
-    if (R > residual_cap) {                                            // no result of the bucket has been written: the host finishes it
-        if (tid == 0) { dcount[b] = 0; const uint32_t o = atomicAdd(&ovf[0], 1u); if (o < OVF_MAX) ovf[2 + o] = (uint32_t)b; }
-        return;
-    }
+    if (R > residual_cap) { give_up(true); return; }
     // residual entry of this lane = a third hash of its table entry: the first of its hash speaks for it (count, rank)
     Residual me{0, 0, 0};
     uint32_t third_cnt = 0, third_rank = 0;
@@ -247,6 +269,7 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
     uint32_t total, run = block_excl_scan(sum, scr, &total);
     const unsigned long long top = (unsigned long long)b << (64 - bbits);
     __syncthreads();                                                   // every nd[] has been read
+    if (stride && total > stride) { give_up(false); return; }          // more distinct hashes than the bucket has slots for its results
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q < per) {
         const int sub = i0 + q;
@@ -269,9 +292,9 @@ __global__ __launch_bounds__(BT) void bk_table_kernel(uint64_t *bk_hash, uint32_
 }
 
 // exclusive scan of the buckets' distinct counts + the run's status = {pairs, distinct hashes, buckets left to the host,
-// buckets over their stride}
+// buckets that need exact placement, pairs sent to the spill list}
 __global__ __launch_bounds__(BT) void bk_dscan_kernel(const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ fill, const uint32_t *__restrict__ start,
-                                                      int B, uint32_t *__restrict__ dstart, const uint32_t *__restrict__ ovf, int64_t *__restrict__ status) {
+                                                      int B, uint32_t *__restrict__ dstart, const uint32_t *__restrict__ ovf, const uint32_t *__restrict__ spill_n, int64_t *__restrict__ status) {
     __shared__ uint32_t scr[17];
     __shared__ unsigned long long pairs;
     if (threadIdx.x == 0) pairs = 0;
@@ -289,6 +312,7 @@ __global__ __launch_bounds__(BT) void bk_dscan_kernel(const uint32_t *__restrict
         status[1] = total;
         status[2] = ovf[0];
         status[3] = ovf[1];
+        status[4] = spill_n ? (int64_t)spill_n[0] : 0;
     }
 }
 
@@ -373,6 +397,7 @@ void bucket_plan(const SketchState &S, int64_t n_reads, int64_t nt, int64_t n_wi
     plan->G = (int)std::min<int64_t>(G_MAX, (nt + 127) / 128);
     plan->stride = S.opt_stride > 0 ? (uint32_t)S.opt_stride : (uint32_t)STRIDE;
     plan->residual_cap = S.opt_residual_cap < 0 ? 0u : S.opt_residual_cap > 0 ? (uint32_t)S.opt_residual_cap : (uint32_t)RCAP;
+    plan->spill_cap = S.opt_spill_cap < 0 ? 0u : S.opt_spill_cap > 0 ? (uint32_t)S.opt_spill_cap : (uint32_t)SPILL_CAP;
     plan->ok = true;
 }
 
@@ -381,9 +406,14 @@ int bucket_fast_begin(dg_ctx *c, SketchState &S, const BucketPlan &plan, BucketE
     const size_t slots = (size_t)plan.B * plan.stride;
     if (int rc = S.d_bk_hash.ensure(8 * slots)) return rc;
     if (int rc = S.d_bk_read.ensure(4 * slots)) return rc;
-    if (int rc = S.d_bk_fill.ensure(4 * ((size_t)plan.B * FILL_PAD + OVF_MAX + 16))) return rc;   // fill counters (a line each) | the table kernel's overflow record
-    DG_HIP(hipMemsetAsync(S.d_bk_fill.p, 0, 4 * ((size_t)plan.B * FILL_PAD + 16), c->stream));     // the one memset of the pass
-    *be = BucketEmit{S.d_bk_fill.as<uint32_t>(), S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), plan.bbits, plan.stride};
+    // fill counters (a line each) | the table kernel's overflow record (2 + OVF_MAX words) | the spill list's counter (a line of its own)
+    if (int rc = S.d_bk_fill.ensure(4 * ((size_t)plan.B * FILL_PAD + OVF_MAX + 48))) return rc;
+    DG_HIP(hipMemsetAsync(S.d_bk_fill.p, 0, 4 * ((size_t)plan.B * FILL_PAD + OVF_MAX + 48), c->stream));   // the one memset of the pass
+    if (int rc = S.d_spill_hash.ensure(8 * (size_t)std::max<uint32_t>(plan.spill_cap, 1))) return rc;
+    if (int rc = S.d_spill_read.ensure(4 * (size_t)std::max<uint32_t>(plan.spill_cap, 1))) return rc;
+    uint32_t *fill = S.d_bk_fill.as<uint32_t>();
+    *be = BucketEmit{fill, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), plan.bbits, plan.stride,
+                     fill + (size_t)plan.B * FILL_PAD + OVF_MAX + 32, S.d_spill_hash.as<uint64_t>(), S.d_spill_read.as<uint32_t>(), plan.spill_cap};
     return DG_OK;
 }
 
@@ -418,17 +448,20 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
     const uint32_t *bstart = fast ? nullptr : S.d_bk_start.as<uint32_t>(), *fill = fast ? S.d_bk_fill.as<uint32_t>() : nullptr;
     uint32_t *dcount = S.d_bk_dcount.as<uint32_t>(), *dstart = S.d_bk_dstart.as<uint32_t>();
     uint32_t *ovf = fast ? S.d_bk_fill.as<uint32_t>() + (size_t)B * FILL_PAD : S.d_bk_ovf.as<uint32_t>();
+    const uint32_t *spill_n = fast ? S.d_bk_fill.as<uint32_t>() + (size_t)B * FILL_PAD + OVF_MAX + 32 : nullptr;
     *outcome = 0;
     if (!fast) DG_HIP(hipMemsetAsync(ovf, 0, 8, s));
     hipLaunchKernelGGL(bk_table_kernel, dim3(B), dim3(BT), table_lds_bytes(plan.sbits), s, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), bstart, fill, stride,
-                       plan.bbits, plan.sbits, plan.residual_cap, plan.has_multi ? 1 : 0, dcount, ovf);
-    hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, S.d_bk_status.as<int64_t>());
+                       plan.bbits, plan.sbits, plan.residual_cap, plan.has_multi ? 1 : 0, dcount, ovf, spill_n, S.d_spill_hash.as<uint64_t>(), S.d_spill_read.as<uint32_t>(),
+                       plan.spill_cap);
+    hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, spill_n, S.d_bk_status.as<int64_t>());
     if (out_hash)                                                      // caller's buffers: gather before the status is known (repeated if the host had to finish buckets)
         hipLaunchKernelGGL(bk_gather_kernel, dim3(B), dim3(256), 0, s, bstart, stride, dcount, dstart, S.d_bk_hash.as<uint64_t>(), S.d_bk_read.as<uint32_t>(), out_hash, out_cnt, cap);
     DG_HIP(hipGetLastError());
-    DG_HIP(hipMemcpyAsync(S.h_status, S.d_bk_status.p, 32, hipMemcpyDeviceToHost, s));
+    DG_HIP(hipMemcpyAsync(S.h_status, S.d_bk_status.p, 40, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
     S.stat_buckets = B;
+    S.stat_spilled = S.h_status[4];
     if (S.h_status[3]) { *outcome = 1; return DG_OK; }                 // a bucket ran over its stride (pairs were dropped)
     const int64_t n_ovf = S.h_status[2];
     S.stat_overflow = n_ovf;
@@ -442,8 +475,8 @@ int bucket_finish(dg_ctx *c, SketchState &S, const BucketPlan &plan, bool fast, 
             const size_t at = fast ? (size_t)b * stride : (size_t)tab[b], n = fast ? tab[(size_t)b * FILL_PAD] : tab[b + 1] - tab[b];
             if (int rc = finish_segment(c, S, (int)b, at, n)) return rc;
         }
-        hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, S.d_bk_status.as<int64_t>());
-        DG_HIP(hipMemcpyAsync(S.h_status, S.d_bk_status.p, 32, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(bk_dscan_kernel, dim3(1), dim3(BT), 0, s, dcount, fill, bstart, B, dstart, ovf, spill_n, S.d_bk_status.as<int64_t>());
+        DG_HIP(hipMemcpyAsync(S.h_status, S.d_bk_status.p, 40, hipMemcpyDeviceToHost, s));
         DG_HIP(hipStreamSynchronize(s));
     }
     const int64_t nd = S.h_status[1];

@@ -157,11 +157,13 @@ int dg_sketch_get_timing(dg_ctx *, dg_sketch_timing *);
  *                          all (hash, read) pairs + reduce-by-key.  The output is the same bit for bit.
  *   bucket_bits b          0 (default): buckets sized to the input; 1..15: 2^b buckets
  *   bucket_stride n        0 (default): 12288 slots per bucket in mode 0
+ *   spill_cap n            0 (default): 2^20 pairs in the shared spill list of full buckets; -1: none (a full bucket repeats the pass
+ *                          with exact placement at once)
  *   residual_cap n         0 (default): 1024 residual entries per bucket (third hashes of a table entry); fewer (-1: none)
  *                          leave more buckets to the host's per-segment finish
  *   host_buckets n         0 (default): up to 256 buckets may be left to the host before the generic path takes over; 1..256
  * dg_sketch_get_stat names, about the last dg_sketch_reads / dg_sketch_reads_dev call: spectrum_path (0 buckets filled by the
- * tile kernel, 1 exact placement, 2 generic), buckets, overflow_buckets (finished by the host per segment) */
+ * tile kernel, 1 exact placement, 2 generic), buckets, overflow_buckets (finished by the host per segment), spilled_pairs */
 int dg_sketch_set_option(dg_ctx *, const char *name, int64_t value);
 int dg_sketch_get_stat(dg_ctx *, const char *name, int64_t *value);
 

@@ -68,7 +68,10 @@ SPECTRUM_MODES = {          # name: (options, spectrum_path expected: 0 tile ker
     "exact_placement": ({"spectrum_mode": 2}, 1),
     "two_buckets": ({"bucket_bits": 1, "bucket_stride": 1 << 20}, 0),
     "32k_buckets": ({"bucket_bits": 15, "bucket_stride": 4096}, 0),
-    "stride_overrun": ({"bucket_bits": 4, "bucket_stride": 512}, 1),                 # a bucket runs over its stride: repeated with exact placement
+    "stride_overrun": ({"bucket_bits": 9, "bucket_stride": 256}, 0),                 # full buckets: their further pairs go through the shared spill list
+    "spill_overrun": ({"bucket_bits": 9, "bucket_stride": 256, "spill_cap": 1000}, 1),   # ... which runs over too: repeated with exact placement
+    "no_spill_list": ({"bucket_bits": 9, "bucket_stride": 256, "spill_cap": -1}, 1),
+    "results_over_stride": ({"bucket_bits": 4, "bucket_stride": 512}, 1),           # more distinct hashes in a bucket than it has slots: exact placement
     "host_segments": ({"bucket_bits": 3, "bucket_stride": 1 << 17, "residual_cap": 1}, 0),                       # residual lists overflow: those buckets are finished per segment with rocPRIM
     "host_segments_exact": ({"spectrum_mode": 2, "bucket_bits": 3, "residual_cap": 1}, 1),
     "too_many_host_segments": ({"bucket_bits": 3, "bucket_stride": 1 << 17, "residual_cap": 1, "host_buckets": 2}, 2),   # more buckets need the host than allowed: the generic sort after all
@@ -88,7 +91,7 @@ def _spectrum_reads(rng):
 
 
 def _reset_spectrum_options(ctx):
-    for key in ("spectrum_mode", "bucket_bits", "bucket_stride", "residual_cap", "host_buckets"):
+    for key in ("spectrum_mode", "bucket_bits", "bucket_stride", "residual_cap", "host_buckets", "spill_cap"):
         ctx.sketch_set_option(key, 0)
 
 
@@ -104,7 +107,7 @@ def test_sketch_spectrum_paths_agree(gpu_ctx, mode):
         for key, v in opts.items():
             gpu_ctx.sketch_set_option(key, v)
         hg, cg = gpu_ctx.sketch_reads(reads, 21, 11)
-        path, ovf = gpu_ctx.sketch_stat("spectrum_path"), gpu_ctx.sketch_stat("overflow_buckets")
+        path, ovf, spilled = gpu_ctx.sketch_stat("spectrum_path"), gpu_ctx.sketch_stat("overflow_buckets"), gpu_ctx.sketch_stat("spilled_pairs")
     finally:
         _reset_spectrum_options(gpu_ctx)
     assert np.array_equal(hg, ho) and np.array_equal(cg, co)
@@ -113,22 +116,28 @@ def test_sketch_spectrum_paths_agree(gpu_ctx, mode):
         assert ovf > 0
     if mode == "buckets":
         assert ovf == 0
+    if mode == "stride_overrun":
+        assert spilled > 0
 
 
 def test_sketch_spectrum_heavy_hitters(gpu_ctx):
-    """a hash held by more reads than a bucket's stride (13,000 copies of one read): the pass is repeated with exact placement,
-    where a bucket may be any size, and this ctx keeps placing exactly afterwards"""
+    """a hash held by more reads than a bucket has slots (13,000 copies of one read): the bucket's further pairs go through the shared
+    spill list; with no room there the pass is repeated with exact placement, and that ctx keeps placing exactly afterwards"""
     rng = np.random.default_rng(77)
     one = _rnd(rng, 150)
     reads = [_rnd(rng, 150) for _ in range(3000)] + [one] * 13000
     ctx = capi.Context(0)
     hg, cg = ctx.sketch_reads(reads, 31, 25)
-    assert ctx.sketch_stat("spectrum_path") == 1 and ctx.sketch_stat("overflow_buckets") == 0
-    ctx.sketch_reads(reads[:5000], 31, 25)
+    assert ctx.sketch_stat("spectrum_path") == 0 and ctx.sketch_stat("spilled_pairs") > 0 and ctx.sketch_stat("overflow_buckets") == 0
+    ctx.sketch_set_option("spill_cap", 100)
+    hx, cx = ctx.sketch_reads(reads, 31, 25)
     assert ctx.sketch_stat("spectrum_path") == 1
+    ctx.sketch_reads(reads[:5000], 31, 25)
+    assert ctx.sketch_stat("spectrum_path") == 1                        # sticky
+    ctx.sketch_set_option("spill_cap", 0)
     ctx.sketch_set_option("spectrum_mode", 1)
     h2, c2 = ctx.sketch_reads(reads, 31, 25)
-    assert np.array_equal(hg, h2) and np.array_equal(cg, c2)
+    assert np.array_equal(hg, h2) and np.array_equal(cg, c2) and np.array_equal(hx, h2) and np.array_equal(cx, c2)
     ho, co = orc.sketch_reads(reads[:3000] + [one], 31, 25)
     h1, c1 = orc.sketch_reads([one], 31, 25)
     want = dict(zip(ho.tolist(), co.tolist()))

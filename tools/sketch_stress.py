@@ -24,7 +24,7 @@ for t in range(n):
     # the read spectrum's routes and bucket geometry at random (round 3): buckets filled by the tile kernel / exact placement, tiny
     # strides and residual lists (host-finished buckets, the give-up route)
     opts = {"spectrum_mode": int(rng.choice([0, 0, 0, 2])), "bucket_bits": int(rng.choice([0, 0, 1, 3, 6])), "bucket_stride": int(rng.choice([0, 0, 0, 64, 1024])),
-            "residual_cap": int(rng.choice([0, 0, 0, 4, -1])), "host_buckets": int(rng.choice([0, 0, 3]))}
+            "residual_cap": int(rng.choice([0, 0, 0, 4, -1])), "host_buckets": int(rng.choice([0, 0, 3])), "spill_cap": int(rng.choice([0, 0, 0, 50, -1]))}
     for key, v in opts.items(): ctx.sketch_set_option(key, v)
     hg, cg = ctx.sketch_reads(reads, k, w)
     paths[ctx.sketch_stat("spectrum_path")] += 1
