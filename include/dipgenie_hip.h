@@ -152,8 +152,8 @@ typedef struct dg_sketch_timing { float kernel_ms, sort_ms, total_ms; int64_t n_
 int dg_sketch_get_timing(dg_ctx *, dg_sketch_timing *);
 /* parity / test knobs of the read spectrum (Sp_R, src/solver.cpp:526-546; none is needed in normal use):
  *   spectrum_mode m        0 (default): the tile kernel drops every minimizer into the bucket of its hash range, one LDS table
- *                          per bucket resolves it (dg_sketch_spectrum.hip); a bucket over its stride repeats the pass with
- *                          exact placement.  2: exact placement at once.  1: the generic path, a stable 64-bit radix sort of
+ *                          per bucket resolves it (dg_sketch_spectrum.hip); full buckets spill into one shared list, and only when
+ *                          that runs over is the pass repeated with exact placement.  2: exact placement at once.  1: the generic path, a stable 64-bit radix sort of
  *                          all (hash, read) pairs + reduce-by-key.  The output is the same bit for bit.
  *   bucket_bits b          0 (default): buckets sized to the input; 1..15: 2^b buckets
  *   bucket_stride n        0 (default): 12288 slots per bucket in mode 0
