@@ -23,9 +23,11 @@ def _md5(p):
     return hashlib.md5(open(p, "rb").read()).hexdigest()
 
 
-def _sharded(gfa, reads, out, js, extra=()):
+def _sharded(gfa, reads, out, js, extra=(), world=1):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    cmd = [sys.executable, "-m", "dipgenie_amd.run_sharded", "--gpus", "1", "--force-collectives", "--backend", "nccl", "-g", gfa, "-r", reads,
+    # one rank: RCCL with the collective path forced; more: every rank on device 0 with gloo (RCCL refuses two ranks on one device)
+    mode = ["--gpus", "1", "--force-collectives", "--backend", "nccl"] if world == 1 else ["--gpus", str(world), "--backend", "gloo", "--device", "0"]
+    cmd = [sys.executable, "-m", "dipgenie_amd.run_sharded", *mode, "-g", gfa, "-r", reads,
            "-o", out, "-J", js, "-t", "16", "-q", *extra]
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -56,3 +58,15 @@ def test_sharded_run_equals_cli_on_mhc24(built_hip, tmp_path_factory):
     assert _md5(tmp / "s30.fa") == _md5(tmp / "c30.fa")
     assert (summ["dp_value"], summ["spectrum"], summ["n_levels"], summ["cells"]) == (cli["dp_value"], cli["spectrum"], cli["n_levels"], cli["cells"])
     assert summ["n_reads"] == n and sum(summ["range_sizes"]) == summ["spectrum"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_run_with_several_ranks_on_one_gpu(built_hip, tmp_path_factory, world):
+    """the same job with the haplotype sketches and the reads really sharded over 2 / 3 processes, all on this box's one GPU (the HIP
+    operations of every rank are the product's; gloo carries the exchange): the reference's FASTA"""
+    cache = os.path.join(os.environ.get("DG_BENCH_CACHE", str(tmp_path_factory.mktemp("rs"))), "mhc24")
+    gfa, reads4, _ = synth.ensure_mhc24(cache)
+    tmp = tmp_path_factory.mktemp(f"rs_w{world}")
+    summ = _sharded(gfa, reads4, str(tmp / "s.fa"), str(tmp / "s.json"), ["-R", "18"], world=world)
+    assert _md5(tmp / "s.fa") == CASES["mhc24_p2"]["fasta_md5"] and summ["dp_value"] == CASES["mhc24_p2"]["dp_value"]
+    assert summ["world"] == world and sum(summ["range_sizes"]) == summ["spectrum"]
