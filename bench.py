@@ -247,7 +247,7 @@ def main():
     # ---------------------------------------------------------------- build + inputs (untimed)
     import __graft_entry__ as ge
     if rank == 0:
-        ge.build(verbose=False, measurement=False)
+        ge.build(verbose=False)
     barrier()
     from dipgenie_amd import capi, synth
     from dipgenie_amd.dist_sketch import HipOps, ShardedSketch, shard_bounds

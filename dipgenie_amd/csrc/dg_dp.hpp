@@ -15,7 +15,8 @@
 //   * score deltas (:604-624) do not depend on r nor on other levels: a launch fills, for every transition that
 //     touches a colour, the T x T matrix delta[e_u][e_v] (uint16), T = #in-edges of the destination level;
 //   * one launch per level (the levels are a dependency chain); the host picks the chunk size RC per level from a
-//     cost model and gives rows with many in-edges cooperative workgroups.
+//     cost model and gives rows with many in-edges cooperative workgroups.  (Several levels per dispatch with row-completion
+//     counters in place of the kernel boundary were built and measured 3-6x slower: profiles/r03_chained_dispatch_ab.txt.)
 #pragma once
 #include <condition_variable>
 #include <atomic>
@@ -42,7 +43,6 @@ constexpr int ROWX_MAX = 64;                            // widest row in-edge ma
 constexpr int DELTA_PER_BLOCK = 256 * 16;
 constexpr int DELTA_PAD = 8;                            // delta[0..8) stays zero: the colourless transitions' slot
 constexpr int32_t CHAIN_CORRUPT = INT32_MIN;            // ChainState::value after a hop left its level
-constexpr int RING = 16;                                // rolling value state: level l lives in slot l % RING (chained dispatches keep up to RING - 1 levels in flight)
 
 struct LevelDesc {                                      // transition (l-1) -> l, indexed by l; passed BY VALUE to the sweep
     int32_t a0, k;                                      // source level: first vertex id, width
@@ -67,17 +67,6 @@ struct LevelDesc {                                      // transition (l-1) -> l
     int32_t dmax;                                       // largest in-degree among the level's vertices (host: choice of RC)
 };
 
-// Chained dispatch (dg_dp_sweep.hip: dp_sweep_chain_kernel): per destination level, what a per-level launch passes as kernel arguments
-struct ChainLevel {
-    const uint4 *rowrec_l; const uint2 *slots_l; const uint32_t *rowx_l; const uint16_t *dm;
-    int32_t rowx_stride, nblocks, n_heavy, rp_k;        // rp_k = RP | k << 13
-    int32_t dT, gx, gy, zc;                             // grid of the level (x: slot-block quads, y: r chunks); zc = 4 * n_heavy where the rows with many in-edges get cooperative workgroups, else 0
-    int32_t a0, bp_nt, n_wg, pad_;                      // first vertex of the source level; stream the back-pointers non-temporally; workgroups of the level
-    uint32_t expect_src, expect_own;                    // a complete row's counter: in the source level / in this level (5 per (x, y) pair)
-    unsigned long long heavy_lo, heavy_hi;
-};
-struct ChainDispatch { int32_t l0, M; uint32_t pre[RING]; int32_t dbg; unsigned long long *probe; };   // levels [l0, l0 + M), M < RING; pre[q] = first workgroup of level l0 + q
-
 struct TraceOut { int32_t value, s_het, n_e, overflow, corrupt, path_score; };   // path_score: sum of the score deltas along the walked path (must equal value)
 struct ChainState { int32_t i, j, r, value; };
 struct ColourCsr { const int64_t *hom_off, *het_off; const int32_t *hom_col, *het_col; };
@@ -87,9 +76,8 @@ struct SweepArgs {                                      // generic sweep kernel
     const uint32_t *in_off, *in_edge, *grp_begin;
     const int32_t *in_dst, *dead_cols;
     const uint16_t *delta, *delta_zero;                 // delta: biased so that delta[d.delta_off] is valid for the resident window
-    char *ring;                                         // state slots, each slot_bytes long, data starts pad_bytes in
+    char *ring;                                         // the two state slots (ping-pong: level l in slot l & 1), each slot_bytes long, data starts pad_bytes in
     size_t slot_bytes, pad_bytes;
-    int ring_mask;
     uint16_t *bp;
     unsigned long long *digest;
     int RP;
@@ -108,7 +96,6 @@ struct FastArgs {                                       // fast sweep kernel
     int RP, pad_bytes;                                  // pad_bytes: front padding of the state buffers
     uint32_t buf_bytes;                                 // size of one padded state buffer (what a buffer resource covers)
     uint32_t slot_bytes;                                // distance between two state slots
-    int ring_mask;                                      // level l lives in slot l & ring_mask
     int *progress;                                      // PfCtl::level: the level whose launch is running (L2 prefetcher)
 #ifdef DG_SWEEP_PROBE
     unsigned long long *probe;                          // measurement build: 8 words per level
@@ -139,32 +126,14 @@ struct DpState {
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's host table construction
     int64_t test_poison_level = 0, test_poison_byte = 0xFF;   // test_poison_*: overwrite one level of the lattice between sweep and walk (tests of the corrupt-lattice path)
-    int64_t use_chain = 0;                              // chain: 1 = consecutive levels in one dispatch with row-completion counters instead of kernel boundaries.
-                                                        // Correct (every digest equal) and measured: 13-27 us per level on MHC-24 against 4.1 us for one launch per level --
-                                                        // the row counters are hot lines (10-30 adds + the polls of 30-90 consumer workgroups each); off by default, DESIGN.md s3.3
-    int64_t chain_rc = 2;                               // chain_rc: recombination counts per task in chained dispatches (1..4)
-    int64_t chain_dbg = 0;                              // (experiments: 1 = no wait, 2 = no counter add, 4 = no record touch)
-    int64_t chain_max = RING - 1;                       // chain_max: levels per chained dispatch (2 .. RING - 1)
-    // two slots (ping-pong: the pair stays in the L2s and the Infinity Cache -- the MHC-24 sweep is 2 % slower over all 16) unless chained
-    // dispatches, which keep up to RING - 1 levels in flight, are switched on
-#ifdef DG_CHAIN
-    int ring_mask() const { return use_chain ? RING - 1 : 1; }
-#else
-    int ring_mask() const { return 1; }
-#endif
-    bool chain_failed = false;                          // a chained dispatch timed out once: per-level launches from then on
-    std::vector<ChainLevel> chain_host;                 // built by the first run after a load / option change
-    int64_t chain_built_rc = 0;
-    const void *chain_built_delta = nullptr;
-    int64_t levels_chained = 0;                         // levels of the last run that went out in chained dispatches
     int64_t host_tables = 0;                            // host_tables: 1 = build the tables on the host and upload them (dg_dp_tables.hip; parity twin of dg_dp_build.hip)
     int64_t bp_nt_min_cells = 262144;                   // bp_nt_min_cells: levels this big stream their back-pointers non-temporally
     int64_t graph_batch = -1;                           // graph_batch: levels per captured hipGraph (0 = plain launches, -1 = the default of 1,000)
     int64_t warm_ahead = 128;                           // warm_ahead: sweep look-ahead, levels per batch (0 = off)
     int64_t sync_every = 0;                             // sync_every: drain the stream every N level launches (profiler aid)
     int64_t l2_prefetch = 6;                            // l2_prefetch: levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
-    int64_t use_lean_chain = 1;                         // lean_chain: 1 the lean walk where the lattice allows it, 0 always the general one, 2 the two-ahead walk (second row records; measured slower, kept for parity runs); next load
-    bool lean_chain = false, pair_chain = false;
+    int64_t use_lean_chain = 1;                         // lean_chain: 1 the lean walk where the lattice allows it, 0 always the general one; next load
+    bool lean_chain = false;
     // single-window score deltas computed beside the sweep: piece k (transitions of levels >= delta_piece_level[k]) signals delta_piece_ev[k]
     std::vector<hipEvent_t> delta_piece_ev;
     std::vector<int32_t> delta_piece_level;
@@ -206,7 +175,7 @@ struct DpState {
     std::vector<int32_t> level_dmax;                    // largest in-degree among the level's vertices
     int64_t n_grp = 0, n_dead = 0, n_heavy_rows = 0, n_slot_records = 0, n_rowx_words = 0, n_dtrans = 0, n_edges = 0;   // logical table sizes (dg_dp_get_table_digest)
     DevBuf d_descs, d_in_off, d_in_edge, d_in_dst, d_hom_off, d_het_off, d_hom_col, d_het_col, d_eflag, d_eself;
-    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowrec2, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl, d_chainlv, d_rowdone, d_chainprobe;
+    DevBuf d_delta, d_bp, d_ring, d_digest, d_trace, d_edges, d_dblk_first, d_dtrans, d_grp, d_dead, d_heavy, d_rowrec, d_rowx, d_slots, d_path, d_ckpt, d_chain, d_pfctl;
 #ifdef DG_SWEEP_PROBE
     DevBuf d_probe;
 #endif
@@ -272,9 +241,6 @@ struct SweepLaunch {                     // per-run launch context
 void sweep_prepare(const DpState &S, SweepLaunch &X);
 void sweep_init_state(const DpState &S, hipStream_t s);                  // level 0: every r starts at 0 (:534-535)
 void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s);
-int sweep_chain_prepare(DpState &S, SweepLaunch &X, hipStream_t s);            // per-level parameters of chained dispatches (device array), counters
-bool sweep_chain_ok(const DpState &S, const SweepLaunch &X, int l);             // level l may be part of a chained dispatch
-void sweep_launch_chain(DpState &S, SweepLaunch &X, int l0, int M, hipStream_t s);   // levels [l0, l0 + M) in one dispatch
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s);
 int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s);
 void sweep_prefetch_end(DpState &S, int le, hipStream_t s);
@@ -285,6 +251,5 @@ void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s);
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s);
 void trace_launch_finish(const DpState &S, hipStream_t s);
 void trace_debug_report(const DpState &S);
-int trace_build_second_records(DpState &S, hipStream_t s);   // rowrec2 of the pair walk, from the row records on the device
 
 }  // namespace dgi

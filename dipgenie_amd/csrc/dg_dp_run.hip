@@ -106,7 +106,7 @@ struct Run {
 
     Run(dg_ctx *c_, DpState &S_) : c(c_), S(S_), s(c_->stream) { sweep_prepare(S, X); }
     int n_win() const { return (int)S.dwin_t.size() - 1; }
-    int32_t *state_ptr(int level) const { return (int32_t *)(S.d_ring.as<char>() + (size_t)(level & S.ring_mask()) * S.state_alloc_bytes) + S.pad_front; }
+    int32_t *state_ptr(int level) const { return (int32_t *)(S.d_ring.as<char>() + (size_t)(level & 1) * S.state_alloc_bytes) + S.pad_front; }
     size_t level_cells(int level) const {               // state size of a level (level 0: the source, k = 1)
         const int64_t k = level == 0 ? 1 : S.descs[level].k2;
         return (size_t)(k * k * S.RP);
@@ -115,13 +115,7 @@ struct Run {
 
     // issues the launches of destination levels [l0, l1) of the range that began at lb
     int issue_levels(int l0, int l1, int lb, int le) {
-#ifdef DG_CHAIN
-        const bool chain = S.use_chain && !S.chain_failed && n_win() == 1 && (int)S.chain_host.size() == S.L;
-#else
-        const bool chain = false;
-#endif
-        const int chain_max = (int)std::min<int64_t>(std::max<int64_t>(S.chain_max, 2), RING - 1);
-        for (int l = l0; l < l1;) {
+        for (int l = l0; l < l1; ++l) {
             if (S.level_win[l] >= 0 && S.level_win[l] != S.cur_win) load_window(S.level_win[l]);
             if (S.warm_ahead > 0 && l >= next_warm && (l == lb || !(S.pf_active && S.pf_far > 0))) {
                 // tables of the batch after this one (and, at the start of a range, of this one too)
@@ -129,13 +123,7 @@ struct Run {
                 if (q1 > q0) sweep_warm_tables(S, X, q0, q1, s);
             }
             if (l >= next_warm) next_warm = l + (int)std::max<int64_t>(S.warm_ahead, 1);
-            int m = 1;
-            if (chain && sweep_chain_ok(S, X, l)) {
-                while (l + m < l1 && m < chain_max && sweep_chain_ok(S, X, l + m)) ++m;
-            }
-            if (m >= 2) sweep_launch_chain(S, X, l, m, s);               // levels [l, l + m) in one dispatch: no kernel boundary between them
-            else sweep_launch_level(S, X, l, s);
-            l += m;
+            sweep_launch_level(S, X, l, s);
             ++n_launch;
             // profiling aid: rocprofv3 --pmc crashes when ~10^5 dispatches are queued without a drain
             if (S.sync_every > 0 && n_launch % S.sync_every == 0) DG_HIP(hipStreamSynchronize(s));
@@ -155,10 +143,6 @@ struct Run {
     int sweep_range(int lb, int le, uint16_t *bp_biased) {
         X.A.bp = bp_biased; X.F.bp = bp_biased;
         next_warm = lb;
-        if (S.use_chain && !S.chain_failed && n_win() == 1 && S.d_rowdone.p) {   // row completion counters of the range's levels start at zero
-            const int64_t v0 = S.descs[lb].a0, v1 = (int64_t)S.descs[le - 1].b0 + S.descs[le - 1].k2;
-            DG_HIP(hipMemsetAsync(S.d_rowdone.as<uint32_t>() + v0, 0, 4 * (size_t)(v1 - v0), s));
-        }
         if (int rc = sweep_prefetch_begin(S, X, lb, le, n_win() == 1, s)) return rc;
         const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : 1000;
         // what issue_levels bakes into a captured batch besides the levels: whether the periodic look-ahead launches are left to the
@@ -266,7 +250,6 @@ struct Run {
         S.delta_piece_next = DELTA_NO_PIECES;
         if (n_win() == 1 && S.n_delta_blocks > 0) X.A.delta = X.F.delta = delta_launch_overlapped(S, s);   // everything fits: the head up front (delta_ms), the rest beside the sweep
         DG_HIP(hipEventRecord(S.ev[1], s));
-        if (n_win() == 1) { if (int rc = sweep_chain_prepare(S, X, s)) return rc; }
         if (S.want_digest) DG_HIP(hipMemsetAsync(S.d_digest.p, 0, 8 * (size_t)S.L, s));
 #ifdef DG_SWEEP_PROBE
         {   // slot 0 of every level takes an atomicMin: start from all ones
@@ -321,23 +304,9 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
     if (int rc = run.wait_for_chunks()) return rc;
     TraceOut to;
     std::vector<int32_t> edges(4 * (size_t)S.cap);
-    for (int attempt = 0;; ++attempt) {
-        memset(S.launch_hist, 0, sizeof S.launch_hist);
-        S.levels_chained = 0;
-        run.n_launch = 0;
-        if (int rc = run.forward_and_trace()) return rc;
-        int chain_abort = 0;
-        DG_HIP(hipMemcpyAsync(&chain_abort, (const char *)S.d_pfctl.p + 5 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, s));   // PfCtl::chain_abort
-        DG_HIP(hipStreamSynchronize(s));
-        if (!chain_abort) break;
-        // a task of a chained dispatch waited too long for a row (workgroups not dispatched in order, or a device too busy to make
-        // progress): the results of that pass are void -- per-level launches from here on
-        if (attempt > 0) { set_error("chained dispatch timed out twice"); return DG_ERR_STATE; }
-        if (getenv("DG_DEBUG")) fprintf(stderr, "[dipgenie_hip] run: a chained dispatch timed out; repeating the pass with one launch per level\n");
-        S.chain_failed = true;
-        graphs_clear(S);
-        DG_HIP(hipMemsetAsync((char *)S.d_pfctl.p + 5 * sizeof(int), 0, sizeof(int), s));
-    }
+    memset(S.launch_hist, 0, sizeof S.launch_hist);
+    run.n_launch = 0;
+    if (int rc = run.forward_and_trace()) return rc;
     DG_HIP(hipMemcpyAsync(&to, S.d_trace.p, sizeof to, hipMemcpyDeviceToHost, s));
     DG_HIP(hipMemcpyAsync(edges.data(), S.d_edges.p, 4 * edges.size(), hipMemcpyDeviceToHost, s));
     if (S.want_digest) {
@@ -358,22 +327,6 @@ static int dp_run(dg_ctx *c, dg_dp_result *res) {
         if (hipStreamSynchronize(S.pf_stream) == hipSuccess && hipMemcpy(w, S.d_pfctl.p, sizeof w, hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[dipgenie_hip] run: L2 table prefetcher covered %d levels (since load)\n", w[2]);
     }
-    if ((S.chain_dbg & 8) && S.d_chainprobe.p) {            // experiments: phases of every level's middle workgroup (100 MHz ticks)
-        std::vector<unsigned long long> pr((size_t)S.L * 4);
-        DG_HIP(hipMemcpy(pr.data(), S.d_chainprobe.p, 8 * pr.size(), hipMemcpyDeviceToHost));
-        double w = 0, t = 0, dr = 0, gap = 0; long n = 0, ng = 0;
-        for (int l = 2; l < S.L; ++l) {
-            const unsigned long long *p = &pr[(size_t)l * 4], *pp = &pr[(size_t)(l - 1) * 4];
-            if (!p[0] || !p[3]) continue;
-            w += (double)(p[1] - p[0]); t += (double)(p[2] - p[1]); dr += (double)(p[3] - p[2]); ++n;
-            if (pp[3] && p[3] > pp[3]) { gap += (double)(p[3] - pp[3]); ++ng; }
-        }
-        if (n) fprintf(stderr, "[dipgenie_hip] chain probe (%ld levels): start -> wait over %.2f us, task %.2f us, drain + barrier %.2f us; signal-to-signal of consecutive levels %.2f us\n", n,
-                       0.01 * w / n, 0.01 * t / n, 0.01 * dr / n, ng ? 0.01 * gap / ng : 0.0);
-    }
-    if (getenv("DG_DEBUG") && S.levels_chained)
-        fprintf(stderr, "[dipgenie_hip] run: %lld levels went out in %lld chained dispatches (%d recombination counts per task)\n", (long long)S.levels_chained,
-                (long long)S.launch_hist[63 * 4 + 3], (int)S.chain_built_rc);
     if (getenv("DG_DEBUG"))
         fprintf(stderr, "[dipgenie_hip] run: host issued %lld sweep launches in %.1f ms (%.2f us each)\n", (long long)run.n_launch, 1e3 * run.host_enqueue_s,
                 1e6 * run.host_enqueue_s / (double)std::max<int64_t>(run.n_launch, 1));
@@ -457,7 +410,6 @@ extern "C" int dg_dp_get_launch_profile(dg_ctx *c, char *buf, int cap) {
         if (!n) continue;
         char item[96];
         if (q == 0) snprintf(item, sizeof item, "dp_sweep_kernel:%lld", (long long)n);
-        else if (q == 63 * 4 + 3) snprintf(item, sizeof item, "dp_sweep_chain_kernel<%d>:%lld", (int)c->dp->chain_built_rc, (long long)n);
         else snprintf(item, sizeof item, "dp_sweep_%s_kernel<%d,%s>:%lld", (q & 1) ? "coop" : "fast", q / 4, (q & 2) ? "general" : "lean", (long long)n);
         if (!out.empty()) out += ' ';
         out += item;
@@ -478,7 +430,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
-        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"chain", &S.use_chain, 0}, {"chain_rc", &S.chain_rc, 1}, {"chain_max", &S.chain_max, 2}, {"chain_dbg", &S.chain_dbg, 0}, {"side_stream", &S.side_stream, -1}, {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
+        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1}, {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
     };
     for (auto &o : plain)
         if (!strcmp(key, o.name)) { *o.field = v < o.lo ? o.lo : v; return DG_OK; }

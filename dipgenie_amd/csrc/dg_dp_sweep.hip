@@ -17,12 +17,8 @@
 
 namespace dgi {
 
-// state slot of a level: ping-pong in the product build (a compile-time mask), a ring in the measurement build with chained dispatches
-#ifdef DG_CHAIN
-#define DG_SLOT(ARGS, LEVEL) ((LEVEL) & (ARGS).ring_mask)
-#else
+// state slot of a level: the two slots are ping-pong buffers
 #define DG_SLOT(ARGS, LEVEL) ((LEVEL) & 1)
-#endif
 
 constexpr unsigned long long DIGEST_PRED_MUL = 0x9E3779B97F4A7C15ULL;   // oracle_dp.cpp: weight of the predecessor term
 
@@ -255,41 +251,9 @@ struct LevelHead {
     uint32_t buf_bytes;
 };
 
-// What a task of a CHAINED dispatch (dp_sweep_chain_kernel: several consecutive levels in one launch, no kernel boundary between them)
-// needs beyond the level's own parameters: where the completion counters of the source level's rows are, what they read when a row is
-// complete, and the flag a timed-out spin raises.
-struct ChainWait {
-    const uint32_t *src_done;           // rowdone + first vertex of the source level
-    uint32_t expect;                    // value of a complete row's counter
-    int *abort_flag;
-};
-
-// ONE wave per workgroup waits (all its waves work on one destination row, hence on the same source rows): lane t < du watches the
-// source row of in-edge t.  A source row is complete when its counter reads `expect` (every workgroup of the row has added its share
-// behind its stores).  `sc1` loads are not served from a stale copy in the reader XCD's L2 -- the poll itself relies on that: it re-reads
-// a word its XCD has read before and does see the update -- so a line shared with a neighbouring, still unfinished row is harmless: the
-// bytes of the finished row in it are final and every gather fetches afresh.  Polls back off (a thousand workgroups watch a few hundred
-// words); a time-out raises the abort flag.
-__device__ __forceinline__ void chain_wait(const ChainWait &cw, int du, uint32_t src_word, int lane, int dbg) {
-    const int src = (int)(src_word & 0x7FFFu);
-    bool pending = lane < du;
-    unsigned spin = 0;
-    while (__builtin_amdgcn_ballot_w64(pending) != 0) {
-        if (pending) pending = __hip_atomic_load(cw.src_done + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cw.expect;
-        if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
-        if (dbg & 16) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(8);
-        if (++spin > (1u << 19) || (spin % 512 == 0 && __hip_atomic_load(cw.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(cw.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the host runs the pass again without chaining)
-            break;
-        }
-    }
-}
-
-template <int RC, bool DIGEST, bool GENERAL, int COOP, bool CHAIN = false>
+template <int RC, bool DIGEST, bool GENERAL, int COOP>
 __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A, const LevelDesc &d, __amdgpu_buffer_rsrc_t cur_rsrc,
-                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr,
-                                           const ChainWait *cw = nullptr) {
-    constexpr int LD_AUX = CHAIN ? 16 : 0;                              // chained: `sc1` gathers (what another workgroup of this launch stored)
+                                           int32_t *__restrict__ nxt, int i2, int g, int r0, int lvl, int part = 0, uint2 *ex = nullptr) {
     const int lane = threadIdx.x & 63;
     const int RP = H.RP;
     DG_PROBE_BEGIN
@@ -320,7 +284,6 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
     if (COOP == 1 && du > COOP_MIN) return;
     DG_PROBE(1);
     const int t_lo = COOP == 2 ? (du * part) >> 2 : 0, t_hi = COOP == 2 ? (du * (part + 1)) >> 2 : du;   // this wave's share of the row's in-edges
-    if (CHAIN) { if (du > 2 && !rowx) { mypu = 0; if (lane < du) mypu = A.in_edge[rr.x + lane]; } }      // (lean levels: in-degree <= 64; the wait itself: chain_wait)
     int bval[RC];
     uint32_t bord[RC];
 #pragma unroll
@@ -348,16 +311,14 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
                 int va[RC], vb[RC];
                 const int dla = (int)dm[erow0 + dcol];
                 int dlb = 0;
-                // (chained: recombination counts outside [0, RP) are clamped into the row -- the select discards them either way, but a
-                // chained task may only touch lines of rows it has waited for)
 #pragma unroll
                 for (int q = 0; q < RC; ++q)
-                    va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, CHAIN ? ((ia * RP + min(max(r0 - wa + q, 0), RP - 1)) * H.k + j) * 4 + H.pad_bytes : offa + q * rowbytes, 0, LD_AUX);
+                    va[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offa + q * rowbytes, 0, 0);
                 if (du == 2) {
                     dlb = (int)dm[erow0 + dT + dcol];
 #pragma unroll
                     for (int q = 0; q < RC; ++q)
-                        vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, CHAIN ? ((ib * RP + min(max(r0 - wb + q, 0), RP - 1)) * H.k + j) * 4 + H.pad_bytes : offb + q * rowbytes, 0, LD_AUX);
+                        vb[q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, offb + q * rowbytes, 0, 0);
                 }
                 relax_select<RC>(va, dla, ord_rank(0, evr), r0, wa, RP, bval, bord);
                 if (du == 2) relax_select<RC>(vb, dlb, ord_rank(1, evr), r0, wb, RP, bval, bord);
@@ -370,7 +331,7 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
             // lean variant: one trip (in-degree <= 64, lane t of mypu = in-edge t); general: 64 in-edges per trip
             for (int c0 = GENERAL ? t_lo : 0; c0 < t_hi; c0 += GENERAL ? 64 : (1 << 30)) {
                 const int tb = GENERAL ? c0 : t_lo, te = GENERAL ? min(c0 + 64, t_hi) : t_hi;
-                if (!rowx && !CHAIN) { mypu = 0; if (c0 + lane < te) mypu = A.in_edge[rr.x + c0 + lane]; }   // (chained: fetched before the wait)
+                if (!rowx) { mypu = 0; if (c0 + lane < te) mypu = A.in_edge[rr.x + c0 + lane]; }
                 for (int t = tb; t < te; t += U) {
                     // the in-edge words live in SGPRs only until the load offset is formed; the select needs just their
                     // weight bits, kept in one mask (a deep step would otherwise hold U scalars and spill)
@@ -387,7 +348,7 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
                                 dl[u] = (int)dm[erow0 + (int64_t)(t + u) * dT + dcol];
 #pragma unroll
                                 for (int q = 0; q < RC; ++q)
-                                    vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, CHAIN ? ((iu * RP + min(max(r0 - w + q, 0), RP - 1)) * H.k + j) * 4 + H.pad_bytes : off + q * rowbytes, 0, LD_AUX);
+                                    vals[u][q] = __builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, off + q * rowbytes, 0, 0);
                             }
                         }
 #pragma unroll
@@ -442,8 +403,7 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
             const int r2 = r0 + q;
             if (r2 < RP) {
                 const int idx = (i2 * RP + r2) * d.k2 + j2;            // fast form: a state buffer is < 2 GB, 32-bit indices
-                if (CHAIN) __hip_atomic_store(&nxt[idx], bval[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // `sc1`: read by other workgroups of this launch
-                else nxt[idx] = bval[q];                               // (plain store: write-through costs +5 %, non-temporal +4.4 % on MHC-24)
+                nxt[idx] = bval[q];                                    // (plain store: write-through costs +5 %, non-temporal +4.4 % on MHC-24)
                 if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], ~bord[q]); else A.bp[d.bp_off + idx] = (uint16_t)~bord[q]; }
                 if (DIGEST && bval[q] != NEG_INF) {                    // (parity runs only: the extra loads are off the product path)
                     const unsigned long long o = ((unsigned long long)r2 * d.k2 + i2) * d.k2 + j2;   // oracle's r-major index
@@ -460,7 +420,7 @@ __device__ __forceinline__ void sweep_task(const LevelHead &H, const FastArgs &A
             const int q = t % RC, c = A.dead_cols[d.dead_first + t / RC];
             if (r0 + q < RP) {
                 const int64_t idx = ((int64_t)i2 * RP + r0 + q) * d.k2 + c;
-                if (CHAIN) __hip_atomic_store(&nxt[idx], NEG_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else nxt[idx] = NEG_INF;
+                nxt[idx] = NEG_INF;
                 if (A.bp) { if (d.bp_nt) store_bp_nt(&A.bp[d.bp_off + idx], 0xFFFFu); else A.bp[d.bp_off + idx] = (uint16_t)0xFFFFu; }
             }
         }
@@ -534,91 +494,6 @@ __global__ __launch_bounds__(256) void dp_sweep_coop_kernel(const uint4 *rowrec_
     sweep_task<RC, DIGEST, GENERAL, 1>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, (int)blockIdx.z - zc, g, r0, lvl);
 }
 
-#ifdef DG_CHAIN
-// ---------------------------------------------------------------------------------------------
-// Chained dispatch: levels [l0, l0 + M) in ONE launch.  The level chain costs one kernel boundary per level (drain, L2 write-back,
-// barrier, dispatch ramp: about half of a level's 4 us); here the boundary between two levels is replaced by per-row completion
-// counters: a task waits only for the rows it gathers from (and their neighbours, see sweep_task), so a level's stragglers delay
-// their own successors only, and the records of a task (kernel-argument equivalents, row / slot records) are fetched while it waits.
-//   * workgroups are numbered level by level; they are dispatched in that order, so whatever a waiting task needs is resident or
-//     ahead of it in the dispatch order (tools/level_floor.hip: rowflag*, 2.08 us per level for a two-round body against 2.37 us for
-//     one graph-replayed launch per level); every wait is bounded, a time-out raises a flag and the host repeats the pass unchained;
-//   * state values go out as `sc1` (write-through) stores and come in as `sc1` loads (MI355X_MICROARCH.md, hand-offs with sc1 loads,
-//     first row): every storing wave drains its stores, the workgroup meets at a barrier, one lane adds the workgroup's share to its
-//     row's counter; 5 per (slot-block quad, r chunk) pair and row -- a row with cooperative workgroups gets 4 x 1 from them and 1
-//     from the ordinary workgroup that skips it;
-//   * M < RING: no state slot is written twice inside a dispatch, and everything older is behind a kernel boundary.
-// ---------------------------------------------------------------------------------------------
-template <int RC, bool DIGEST>
-__global__ __launch_bounds__(256) void dp_sweep_chain_kernel(const ChainLevel *__restrict__ lv, ChainDispatch D, FastArgs A, uint32_t *__restrict__ rowdone, int *abort_flag,
-                                                             const LevelDesc *__restrict__ descs, const int32_t *__restrict__ heavy_rows) {
-    __shared__ uint2 ex[3 * RC * 64];
-    const uint32_t b = blockIdx.x;
-    int q = 0;
-    for (int t = 1; t < D.M; ++t) q += b >= D.pre[t];
-    q = __builtin_amdgcn_readfirstlane(q);
-    const int lvl = D.l0 + q;
-    const uint32_t local = b - D.pre[q];
-    const ChainLevel C = lv[lvl];
-    const LevelDesc d0 = descs[lvl];
-    LevelDesc d = d0;
-    d.bp_nt = C.bp_nt;
-    const uint32_t gxy = (uint32_t)(C.gx * C.gy);
-    const int z = (int)(local / gxy), rem = (int)(local - (uint32_t)z * gxy), y = rem / C.gx, x = rem - y * C.gx;
-    const int32_t *cur = (const int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl - 1) * A.slot_bytes);
-    int32_t *nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
-    const LevelHead H{C.rowrec_l, C.slots_l, C.rowx_l, cur, C.dm, C.rowx_stride, C.rp_k & 0x1FFF, C.rp_k >> 13, A.pad_bytes, C.dT, A.buf_bytes};
-    if (local == 0 && threadIdx.x == 0) __hip_atomic_store(A.progress, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const ChainWait cw{rowdone + C.a0, C.expect_src, abort_flag};
-    const bool probe_on = (D.dbg & 8) && D.probe && local == (uint32_t)C.n_wg / 2 && threadIdx.x == 0;   // (experiments: the level's middle workgroup stamps its phases)
-    if (probe_on) D.probe[(size_t)lvl * 4] = __builtin_amdgcn_s_memrealtime();
-    const int r0 = y * RC;
-    const int RPv = C.rp_k & 0x1FFF, lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    int row, weight, g;
-    const bool coop_region = z < C.zc;
-    if (coop_region) {                                                  // cooperative region: four waves share (heavy row, slot block)
-        const int h = z >> 2;
-        g = x * 4 + (z & 3);
-        if (h < 4) row = (int)((C.heavy_lo >> (16 * h)) & 0xFFFFu);
-        else if (h < HEAVY_INLINE) row = (int)((C.heavy_hi >> (16 * (h - 4))) & 0xFFFFu);
-        else row = heavy_rows[d.heavy_first + h];
-    } else {
-        row = z - C.zc;
-        g = x * 4 + wave;
-    }
-    // every wave touches the records its task starts with (they are in its CU's cache when the wait is over); wave 0 learns the row's
-    // sources from them and waits for those rows
-    const uint4 rr = C.rowrec_l[row];
-    const int du = (int)rr.y;
-    {
-        const uint2 sl = C.slots_l[min(g, C.nblocks - 1) * 64 + lane];
-        asm volatile("" ::"v"(sl.x), "v"(sl.y));
-    }
-    weight = coop_region ? 1 : ((C.zc > 0 && du > COOP_MIN) ? 1 : 5);
-    if (q > 0 && !(D.dbg & 1)) {
-        if (wave == 0) {
-            uint32_t w = lane == 0 ? rr.z : rr.w;
-            if (du > 2) w = C.rowx_stride > 0 ? (lane < C.rowx_stride ? C.rowx_l[row * C.rowx_stride + lane] : 0u) : (lane < du ? A.in_edge[rr.x + lane] : 0u);
-            chain_wait(cw, min(du, 64), w, lane, D.dbg);
-        }
-        __syncthreads();
-    }
-    if (probe_on) D.probe[(size_t)lvl * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    if (g < C.nblocks && r0 < RPv) {
-        if (coop_region) sweep_task<RC, DIGEST, false, 2, true>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, row, g, r0, lvl, wave, ex, &cw);
-        else if (C.zc > 0) sweep_task<RC, DIGEST, false, 1, true>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, row, g, r0, lvl, 0, nullptr, &cw);
-        else sweep_task<RC, DIGEST, false, 0, true>(H, A, d, state_rsrc(cur, A.buf_bytes), nxt, row, g, r0, lvl, 0, nullptr, &cw);
-    }
-    // this workgroup's stores are on their way: drained by every wave, then one lane tells the row's counter
-    if (probe_on) D.probe[(size_t)lvl * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (probe_on) D.probe[(size_t)lvl * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && !(D.dbg & 2)) __hip_atomic_fetch_add(rowdone + d.b0 + row, (uint32_t)weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-#endif  // DG_CHAIN
-
 // Sweep look-ahead: streams the graph tables (row records, slot records, in-edges, score deltas) of a batch of upcoming
 // levels through the memory-side Infinity Cache.  Every table byte is read exactly once per pass, so without this each
 // level's two dependent load rounds go all the way to HBM; the batch is a few MB, read at full chip bandwidth.
@@ -646,7 +521,7 @@ __global__ __launch_bounds__(256) void dp_warm_tables_kernel(WarmRanges W) {
 // appears, or after 0.3 ms without progress.
 constexpr int PF_WORKGROUPS = 16, PF_FAR_WORKGROUPS = 16;
 constexpr unsigned long long PF_IDLE_TICKS = 30000;      // 0.3 ms
-struct PfCtl { int seq, stop, levels_done, probe, probe_ok, chain_abort, pad_[26]; int level; int pad2_[31]; };      // level: a line of its own; chain_abort: a chained dispatch timed out
+struct PfCtl { int seq, stop, levels_done, probe, probe_ok, pad_[27]; int level; int pad2_[31]; };      // level: a line of its own
 
 __global__ void dp_pf_ctl_kernel(PfCtl *c, int seq, int level, int stop) {
     __hip_atomic_store(&c->level, level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -729,12 +604,12 @@ void sweep_prepare(const DpState &S, SweepLaunch &X) {
     A.descs = S.d_descs.as<LevelDesc>(); A.in_off = S.d_in_off.as<uint32_t>(); A.in_edge = S.d_in_edge.as<uint32_t>();
     A.grp_begin = S.d_grp.as<uint32_t>(); A.in_dst = S.d_in_dst.as<int32_t>(); A.dead_cols = S.d_dead.as<int32_t>();
     A.delta = A.delta_zero = S.d_delta.as<uint16_t>();
-    A.ring = S.d_ring.as<char>(); A.slot_bytes = S.state_alloc_bytes; A.pad_bytes = 4 * (size_t)S.pad_front; A.ring_mask = S.ring_mask();
+    A.ring = S.d_ring.as<char>(); A.slot_bytes = S.state_alloc_bytes; A.pad_bytes = 4 * (size_t)S.pad_front;
     A.bp = nullptr; A.digest = S.d_digest.as<unsigned long long>(); A.RP = S.RP;
     FastArgs &F = X.F;
     F.rowrec = S.d_rowrec.as<uint4>(); F.slots = S.d_slots.as<uint2>(); F.in_edge = A.in_edge; F.rowx = S.d_rowx.as<uint32_t>(); F.dead_cols = A.dead_cols;
     F.delta = F.delta_zero = A.delta; F.bp = nullptr; F.digest = A.digest; F.RP = S.RP;
-    F.ring = S.d_ring.as<char>(); F.slot_bytes = (uint32_t)S.state_alloc_bytes; F.ring_mask = S.ring_mask();
+    F.ring = S.d_ring.as<char>(); F.slot_bytes = (uint32_t)S.state_alloc_bytes;
 #ifdef DG_SWEEP_PROBE
     F.probe = S.d_probe.as<unsigned long long>();
 #endif
@@ -828,90 +703,6 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
 #undef DG_SWEEP
     }
 }
-
-#ifdef DG_CHAIN
-// ---- chained dispatches (dp_sweep_chain_kernel) ----
-// cooperative workgroups for the level's fan-in rows at a given chunk size?  (the cost model of choose_rc at a fixed RC)
-static bool chain_coop(const DpState &S, const LevelDesc &d, int l, int rc) {
-    if (!S.use_coop || d.n_heavy <= 0) return false;
-    if (S.use_coop == 2) return true;
-    const double dmax = (double)std::max(1, S.level_dmax[l]);
-    double T[2];
-    for (int pass = 0; pass < 2; ++pass) {
-        const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
-        const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
-        const double W = rows * d.nblocks * ((S.RP + rc - 1) / rc);
-        T[pass] = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + chain * rc * (double)S.rc_tg_ps * 1e-3) + W * (double)S.rc_tw_ps * 1e-3;
-    }
-    return T[1] <= T[0];
-}
-
-bool sweep_chain_ok(const DpState &S, const SweepLaunch &X, int l) {
-    if (!S.use_chain || S.chain_failed || !S.use_fast || !X.small_state || S.RP > 8191 || (int)S.chain_host.size() != S.L) return false;
-    const LevelDesc &d = S.descs[l];
-    if (d.fast_ok != 1 || d.k >= (1 << 15) || d.k2 >= (1 << 15)) return false;
-    // the throughput-bound levels (more waves than two rounds of resident ones) keep their own launches and their big chunks: the
-    // kernel boundary is a small part of them
-    return (double)S.chain_host[l].n_wg * 4.0 <= 2.0 * (double)S.rc_cap;
-}
-
-int sweep_chain_prepare(DpState &S, SweepLaunch &X, hipStream_t s) {
-    if (!S.use_chain || S.chain_failed) return DG_OK;
-    const int rc = (int)std::min<int64_t>(std::max<int64_t>(S.chain_rc, 1), 4);
-    if (int e = S.d_rowdone.ensure(4 * ((size_t)S.nV + 64))) return e;
-    if (S.chain_dbg & 8) { if (int e = S.d_chainprobe.ensure(32 * (size_t)S.L)) return e; DG_HIP(hipMemsetAsync(S.d_chainprobe.p, 0, 32 * (size_t)S.L, s)); }
-    if ((int)S.chain_host.size() == S.L && S.chain_built_rc == rc && X.F.delta == S.chain_built_delta) return DG_OK;
-    const FastArgs &F = X.F;
-    S.chain_host.assign(S.L, ChainLevel{});
-    const int nch = (S.RP + rc - 1) / rc;
-    for (int l = 1; l < S.L; ++l) {
-        const LevelDesc &d = S.descs[l];
-        ChainLevel &C = S.chain_host[l];
-        C.rowrec_l = F.rowrec + d.b0; C.slots_l = F.slots + d.slot_first; C.rowx_l = F.rowx + d.rowx_off;
-        C.dT = d.delta_off >= 0 ? d.T : 0;
-        C.dm = C.dT ? F.delta + d.delta_off - (int64_t)d.in_base * C.dT : F.delta_zero;
-        C.rowx_stride = d.rowx_stride; C.nblocks = d.nblocks; C.n_heavy = d.n_heavy; C.rp_k = S.RP | (d.k << 13);
-        C.gx = (d.nblocks + 3) / 4; C.gy = nch;
-        C.zc = chain_coop(S, d, l, rc) ? 4 * d.n_heavy : 0;
-        C.a0 = d.a0; C.bp_nt = (int64_t)d.k2 * d.k2 * S.RP >= S.bp_nt_min_cells ? 1 : 0;
-        C.n_wg = C.gx * C.gy * (d.k2 + C.zc);
-        C.expect_own = 5u * (uint32_t)(C.gx * C.gy);
-        C.expect_src = l > 1 ? S.chain_host[l - 1].expect_own : 0;
-        unsigned long long hlo = 0, hhi = 0;
-        for (int q = 0; q < 4; ++q) { hlo |= (unsigned long long)(uint16_t)d.heavy_in[q] << (16 * q); hhi |= (unsigned long long)(uint16_t)d.heavy_in[4 + q] << (16 * q); }
-        C.heavy_lo = hlo; C.heavy_hi = hhi;
-    }
-    if (int e = S.d_chainlv.ensure(sizeof(ChainLevel) * (size_t)S.L)) return e;
-    DG_HIP(hipMemcpyAsync(S.d_chainlv.p, S.chain_host.data(), sizeof(ChainLevel) * (size_t)S.L, hipMemcpyHostToDevice, s));
-    DG_HIP(hipStreamSynchronize(s));
-    S.chain_built_rc = rc; S.chain_built_delta = X.F.delta;
-    return DG_OK;
-}
-
-void sweep_launch_chain(DpState &S, SweepLaunch &X, int l0, int M, hipStream_t s) {
-    ChainDispatch D{};
-    D.l0 = l0; D.M = M; D.dbg = (int32_t)S.chain_dbg; D.probe = (S.chain_dbg & 8) ? S.d_chainprobe.as<unsigned long long>() : nullptr;
-    uint32_t run = 0;
-    for (int q = 0; q < M; ++q) { D.pre[q] = run; run += (uint32_t)S.chain_host[l0 + q].n_wg; }
-    for (int q = M; q < RING; ++q) D.pre[q] = run;
-    const int rc = (int)S.chain_built_rc;
-    const ChainLevel *lv = S.d_chainlv.as<ChainLevel>();
-    uint32_t *rowdone = S.d_rowdone.as<uint32_t>();
-    int *abort_flag = &S.d_pfctl.as<PfCtl>()->chain_abort;
-    S.launch_hist[63 * 4 + 3]++;
-    S.levels_chained += M;
-#define DG_CHAIN_LAUNCH(RCV, DG) hipLaunchKernelGGL((dp_sweep_chain_kernel<RCV, DG>), dim3(run), dim3(256), 0, s, lv, D, X.F, rowdone, abort_flag, S.d_descs.as<LevelDesc>(), S.d_heavy.as<int32_t>())
-#define DG_CHAIN_RC(DG) do { switch (rc) { case 1: DG_CHAIN_LAUNCH(1, DG); break; case 2: DG_CHAIN_LAUNCH(2, DG); break; case 3: DG_CHAIN_LAUNCH(3, DG); break; default: DG_CHAIN_LAUNCH(4, DG); break; } } while (0)
-    if (S.want_digest) DG_CHAIN_RC(true); else DG_CHAIN_RC(false);
-#undef DG_CHAIN_RC
-#undef DG_CHAIN_LAUNCH
-}
-
-#else   // the product library is built without the chained dispatches (measured 3-6x slower): `make chain` builds them
-bool sweep_chain_ok(const DpState &, const SweepLaunch &, int) { return false; }
-int sweep_chain_prepare(DpState &, SweepLaunch &, hipStream_t) { return DG_OK; }
-void sweep_launch_chain(DpState &, SweepLaunch &, int, int, hipStream_t) {}
-#endif  // DG_CHAIN
 
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s) {   // graph tables of destination levels [q0, q1) -> Infinity Cache
     const LevelDesc &da = S.descs[q0], &db = S.descs[q1 - 1];

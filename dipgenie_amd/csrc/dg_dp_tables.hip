@@ -559,15 +559,11 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
         max_k = B.max_k;
         lap("table uploads");
     }
-    // the two-ahead walk of the traceback (option lean_chain = 2) wants a second record per vertex (16 B); beyond 2 GB of them the lean walk does
-    S.pair_chain = S.lean_chain && S.use_lean_chain >= 2 && (size_t)nV * 16 <= ((size_t)2 << 30);
-    if (S.pair_chain) { if (int rc = trace_build_second_records(S, s)) return rc; }
-    else S.d_rowrec2.release();
     S.n_dtrans = (int64_t)dtrans.size();
     S.n_edges = g->out_off[nV];
     plan_delta_windows(S, dtrans, dblk_first);
     const size_t n_edges = (size_t)g->out_off[nV];
-    const size_t st_bytes = (size_t)S.max_level_cells * 4 * RING, dl_bytes = (size_t)S.delta_buf_entries * 2;
+    const size_t st_bytes = (size_t)S.max_level_cells * 4 * 2, dl_bytes = (size_t)S.delta_buf_entries * 2;
     size_t bp_bytes = 0, ck_bytes = 0;
     // (the tables are allocated already; what follows: edge flags + self scores, digests, the path)
     if (int rc = plan_lattice(c, S, st_bytes, dl_bytes, 3 * n_edges + 16 * (size_t)L + (1 << 20), bp_bytes, ck_bytes, dbg)) return rc;
@@ -585,8 +581,8 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     S.pad_front = 2 * (int64_t)max_k;
     const size_t pad_bytes = 4 * (size_t)(S.pad_front + 33 * (int64_t)max_k);
     S.state_alloc_bytes = (((size_t)S.max_level_cells * 4 + pad_bytes) + 255) & ~(size_t)255;   // one slot
-    if (int rc = S.d_ring.ensure(S.state_alloc_bytes * RING)) return rc;
-    DG_HIP(hipMemsetAsync(S.d_ring.p, 0, S.state_alloc_bytes * RING, s));
+    if (int rc = S.d_ring.ensure(S.state_alloc_bytes * 2)) return rc;          // the two ping-pong slots
+    DG_HIP(hipMemsetAsync(S.d_ring.p, 0, S.state_alloc_bytes * 2, s));
     if (int rc = S.d_digest.ensure(8 * (size_t)L)) return rc;
 #ifdef DG_SWEEP_PROBE
     if (int rc = S.d_probe.ensure(64 * (size_t)L)) return rc;

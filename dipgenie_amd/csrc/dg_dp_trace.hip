@@ -231,12 +231,12 @@ __device__ __forceinline__ void lean_step(LeanWalk &W, int RP, const LeanDesc &N
 constexpr int LEAN_AHEAD_MAX = 96, LEAN_AHEAD_BYTES = 3 << 19;      // window: at most 96 levels and ~1.5 MB of planes
 constexpr int LEAN_PREFETCHERS = 8, LEAN_BLOCKS = 80, LEAN_POLL_EVERY = 4;
 constexpr int LEAN_PUBLISH_MASK = 8;             // the walker publishes its position every 16 levels (every 8: 47.0 ms, 16: 44.5, 32: 44.9 on MHC-24)
-struct ChainSync { unsigned long long pos; int r, xcc; int ticket[2]; int n_helpers, n_levels, n_restarts, n_exact; };   // (the last two: DG_DEBUG statistics)
+struct ChainSync { unsigned long long pos; int r, xcc; int ticket[2]; int n_helpers, n_levels, pad_[2]; };   // (n_helpers, n_levels: DG_DEBUG statistics)
 
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ void lean_prefetch(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, const uint16_t *__restrict__ bp,
-                                              const char *__restrict__ rowrec, ChainSync *sy, int seq, int *dump /* LDS, 64 words */, int lane, const char *__restrict__ rowrec2 = nullptr) {
+                                              const char *__restrict__ rowrec, ChainSync *sy, int seq, int *dump /* LDS, 64 words */, int lane) {
     // a load whose data nobody wants: straight into an LDS dump word per lane -- no destination register that a later value
     // could be sharing when the data arrives, nothing to wait for
 #define DG_DROP_LOAD(PTR) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(PTR), (__attribute__((address_space(3))) void *)dump, 4, 0, 0)
@@ -290,7 +290,6 @@ __device__ __forceinline__ void lean_prefetch(const LevelDesc *__restrict__ desc
             for (int t = lane; t < ((k2 * 16 + 127) >> 7); t += 64) {
                 const uint32_t off = ((uint32_t)b0 << 4) + (uint32_t)min(t << 7, k2 * 16 - 4);
                 DG_DROP_LOAD(rowrec + off);
-                if (rowrec2) DG_DROP_LOAD(rowrec2 + off);
             }
             ++done;
         }
@@ -365,203 +364,6 @@ __global__ __launch_bounds__(64) void dp_trace_chain_lean_kernel(const LevelDesc
 #undef DG_PUBLISH
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two-ahead walk.  The lean walk above still chases one pointer per level: the candidates of level l - 1 are the
-// in-neighbours of the cell's row and column vertices, known only when the row records of level l have arrived -- one L2
-// round trip (0.32 us) per level however the back-pointers are speculated.  A second record per vertex breaks that chain:
-// rowrec2[v] = the first two in-edge words of v's first two in-neighbours (dp_rowrec2_kernel, built at load time).  With
-// the records of the cell c(T) in registers the walk knows c(T + 1) at once (the back-pointer came with the records) and
-// the SIXTEEN possible cells c(T + 2) -- (rank of the hop T -> T + 1) x (rank of the hop T + 1 -> T + 2), for row and
-// column -- and issues records + back-pointer of all sixteen, one per lane.  What step T consumes was issued at step T - 2:
-// two round trips are in flight and a step waits for neither as long as two steps take longer than one round trip, so the
-// walk runs at its instruction count (~90 per level) instead of at the memory latency.
-//   lane bits of the set issued at step T (for level T + 2): 0-1 = ranks (row, column) of hop T -> T + 1, 2-3 = ranks of hop
-//   T + 1 -> T + 2; the lane holding c(T + 2) is e(T) | e(T + 1) << 2.
-// Ranks above 1 (3 % of the vertices have more than two in-edges), the start of a call and anything else that leaves the
-// fast loop go through restart(): one exact step per level until the slot is even, exact loads of the cell, a REFILL step
-// (it also issues the other register set: the four candidates of the next level from the first-hop words, ranks in lane
-// bits 2-3) and one ordinary step.  The fast loop itself is straight-line (hand-unrolled pairs, both register sets issue the
-// same five loads on every path) so that the compiler's wait counts let the younger set stay in flight.
-struct Lean2Regs { uint4 row, row2, col, col2; uint32_t b; };
-struct Lean2Walk { int r, sel, e_prev, n_restarts, n_exact; bool bad, slow; uint32_t pu, pv; };
-
-__device__ __forceinline__ void lean2_issue_cell(Lean2Regs &Y, const LeanDesc &D, const char *__restrict__ rowrec, const char *__restrict__ rowrec2, uint32_t rp_k2,
-                                                 uint32_t ci, uint32_t cj, uint32_t cr) {
-    const uint32_t off = __umul24(ci, rp_k2) + __umul24(cr, D.k2) + cj, vi = (D.b0 + ci) << 4, vj = (D.b0 + cj) << 4;
-    Y.row = *(const uint4 *)(rowrec + vi);
-    Y.row2 = *(const uint4 *)(rowrec2 + vi);
-    Y.col = *(const uint4 *)(rowrec + vj);
-    Y.col2 = *(const uint4 *)(rowrec2 + vj);
-    Y.b = *(const uint16_t *)((const char *)D.bp_level + (off << 1));
-}
-
-#define DG_RL(V, L) ((uint32_t)__builtin_amdgcn_readlane((int)(V), (L)))
-// step of slot T: X holds the set of level T (cell in lane W.sel), issued two steps ago; the hop is parked, the set of level
-// T + 2 goes into X again (N2: its level).  REFILL: the other set Y is (re)built too, for level T + 1 (N1).  A rank above 1
-// leaves everything untouched and raises W.slow.
-template <bool REFILL>
-__device__ __forceinline__ void lean2_step(Lean2Walk &W, int RP, const LeanDesc &N1, const LeanDesc &N2, const char *__restrict__ rowrec, const char *__restrict__ rowrec2,
-                                           uint32_t &park_u, uint32_t &park_v, int slot, int lane, Lean2Regs &X, Lean2Regs &Y) {
-    const uint32_t GUARD = 0xFFFFFFFFu;
-    const int sel = __builtin_amdgcn_readfirstlane(W.sel);
-    const uint32_t bv = DG_RL(X.b, sel), eu = bv >> 8, ev = bv & 0xFFu;
-    const bool slow = (eu | ev) > 1u;                                   // (no early exit: every path issues the same loads, see above)
-    const uint32_t riy = DG_RL(X.row.y, sel), rjy = DG_RL(X.col.y, sel);
-    const uint32_t riz = DG_RL(X.row.z, sel), riw0 = DG_RL(X.row.w, sel), riw = riy > 1u ? riw0 : GUARD;
-    const uint32_t rjz = DG_RL(X.col.z, sel), rjw0 = DG_RL(X.col.w, sel), rjw = rjy > 1u ? rjw0 : GUARD;
-    const uint32_t r2x = DG_RL(X.row2.x, sel), r2y = DG_RL(X.row2.y, sel), r2z = DG_RL(X.row2.z, sel), r2w = DG_RL(X.row2.w, sel);
-    const uint32_t c2x = DG_RL(X.col2.x, sel), c2y = DG_RL(X.col2.y, sel), c2z = DG_RL(X.col2.z, sel), c2w = DG_RL(X.col2.w, sel);
-    // this lane's hypothesis: hop T -> T + 1 by ranks (lane & 1, lane >> 1 & 1), hop T + 1 -> T + 2 by ranks (lane >> 2 & 1, lane >> 3 & 1)
-    const bool ar = lane & 1, ac = lane & 2, mr = lane & 4, mc = lane & 8;
-    const uint32_t wa1 = ar ? riw : riz, wb1 = ac ? rjw : rjz;
-    const uint32_t wa2 = ar ? (mr ? r2w : r2z) : (mr ? r2y : r2x), wb2 = ac ? (mc ? c2w : c2z) : (mc ? c2y : c2x);
-    if (REFILL) {                                                       // level T + 1: first-hop candidates, ranks in lane bits 2-3
-        const uint32_t fa = mr ? riw : riz, fb = mc ? rjw : rjz;
-        lean2_issue_cell(Y, N1, rowrec, rowrec2, (uint32_t)RP * N1.k2, min(fa & 0x7FFFu, N1.k2 - 1u), min(fb & 0x7FFFu, N1.k2 - 1u),
-                         (uint32_t)max(W.r - (int)(fa >> 31) - (int)(fb >> 31), 0));
-    }
-    lean2_issue_cell(X, N2, rowrec, rowrec2, (uint32_t)RP * N2.k2, min(wa2 & 0x7FFFu, N2.k2 - 1u), min(wb2 & 0x7FFFu, N2.k2 - 1u),
-                     (uint32_t)max(W.r - (int)(wa1 >> 31) - (int)(wb1 >> 31) - (int)(wa2 >> 31) - (int)(wb2 >> 31), 0));
-    const uint32_t pu = eu ? riw : riz, pv = ev ? rjw : rjz;
-    const int e = (int)((eu & 1u) | ((ev & 1u) << 1));
-    // a rank above 1 leaves the walk where it was (restart() redoes the slot): selects, not branches
-    W.r = slow ? W.r : W.r - (int)(pu >> 31) - (int)(pv >> 31);
-    W.pu = slow ? W.pu : pu; W.pv = slow ? W.pv : pv;
-    W.sel = W.e_prev | (e << 2);
-    W.e_prev = e;
-    W.slow = slow;
-    const bool mine = lane == slot && !slow;
-    park_u = mine ? pu : park_u;
-    park_v = mine ? pv : park_v;
-}
-
-// one level the plain way (exact loads of the cell, any rank): restart() uses it to get past what the fast loop cannot take
-__device__ __forceinline__ void lean2_exact_step(Lean2Walk &W, int RP, const LeanDesc &D, const char *__restrict__ rowrec, const uint32_t *__restrict__ in_edge,
-                                                 uint32_t &park_u, uint32_t &park_v, int slot, int lane) {
-    const uint32_t ci = min(W.pu & 0x7FFFu, D.k2 - 1u), cj = min(W.pv & 0x7FFFu, D.k2 - 1u);
-    const uint4 rr = *(const uint4 *)(rowrec + ((D.b0 + ci) << 4)), rc = *(const uint4 *)(rowrec + ((D.b0 + cj) << 4));
-    const uint32_t off = __umul24(ci, (uint32_t)RP * D.k2) + __umul24((uint32_t)max(W.r, 0), D.k2) + cj;
-    const uint32_t bv = *(const uint16_t *)((const char *)D.bp_level + (off << 1)), eu = bv >> 8, ev = bv & 0xFFu;
-    uint32_t pu = 0, pv = 0;
-    if (eu >= rr.y || ev >= rc.y) W.bad = true;
-    else {
-        pu = eu == 0 ? rr.z : (eu == 1 ? rr.w : in_edge[rr.x + eu]);
-        pv = ev == 0 ? rc.z : (ev == 1 ? rc.w : in_edge[rc.x + ev]);
-        pu = (uint32_t)__builtin_amdgcn_readfirstlane((int)pu); pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv);
-    }
-    W.r -= (int)(pu >> 31) + (int)(pv >> 31);
-    W.pu = pu; W.pv = pv;
-    park_u = lane == slot ? pu : park_u;
-    park_v = lane == slot ? pv : park_v;
-}
-
-__global__ __launch_bounds__(64) void dp_trace_chain_lean2_kernel(const LevelDesc *__restrict__ descs, int l_hi, int l_lo, int RP, int R,
-                                                                  const uint16_t *__restrict__ bp /* biased by the segment's first unit */,
-                                                                  const int32_t *__restrict__ final_val /* non-null on the first call */,
-                                                                  const uint4 *__restrict__ rowrec_, const uint4 *__restrict__ rowrec2_, const uint32_t *__restrict__ in_edge,
-                                                                  uint2 *__restrict__ path, ChainState *st, ChainSync *sy, int seq) {
-    __shared__ int dump_s[64];
-    const int lane = threadIdx.x & 63;
-    const char *rowrec = (const char *)rowrec_, *rowrec2 = (const char *)rowrec2_;
-    if (blockIdx.x != 0) { lean_prefetch(descs, l_hi, l_lo, RP, bp, rowrec, sy, seq, dump_s, lane, rowrec2); return; }
-    int value, si, sj;
-    Lean2Walk W;
-    W.sel = 0; W.e_prev = 0; W.bad = false; W.slow = false; W.n_restarts = 0; W.n_exact = 0;
-    if (final_val) { value = final_val[(int64_t)R * descs[l_hi].k2]; si = 0; sj = 0; W.r = R; }
-    else { si = st->i; sj = st->j; W.r = st->r; value = st->value; }
-    W.pu = (uint32_t)si; W.pv = (uint32_t)sj;                          // the cell of the slot in hand, as the hop words that led to it
-#define DG_PUBLISH(LV, RV) do { __hip_atomic_store(&sy->r, (RV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-                                __hip_atomic_store(&sy->pos, ((unsigned long long)(uint32_t)seq << 32) | (uint32_t)(LV), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-    if (lane == 0) {
-        __hip_atomic_store(&sy->ticket[(seq + 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sy->xcc, xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DG_PUBLISH((value != NEG_INF && value != CHAIN_CORRUPT) ? l_hi : INT32_MIN, W.r);
-    }
-    if (value != NEG_INF && value != CHAIN_CORRUPT) {
-        Lean2Regs A, B;
-        bool primed = false;                                           // A / B hold the sets of slots t / t + 1 (t even)
-        for (int base = l_hi; base >= l_lo && !W.bad; base -= 56) {
-            const int my_l = max(base - lane, l_lo);                   // 64 descriptors, 56 levels per window; the range's first level
-            const LevelDesc &dd = descs[my_l];                          // stands in for what lies below it (clamped loads only)
-            const int64_t ba = dd.bp_off * 2;
-            int ba_lo = (int)ba, ba_hi = (int)(ba >> 32), kk = dd.k2, bb = dd.b0;
-            asm volatile("" ::"v"(ba_lo), "v"(ba_hi), "v"(kk), "v"(bb)); // descriptors complete before the walk (no wait inside the loop)
-            const int n = min(56, base - l_lo + 1);
-            uint32_t park_u = 0, park_v = 0;
-#define DG_DESC(T) LeanDesc{(const uint16_t *)((const char *)bp + (((int64_t)__builtin_amdgcn_readlane(ba_hi, (T)) << 32) | (uint32_t)__builtin_amdgcn_readlane(ba_lo, (T)))), \
-                           (uint32_t)__builtin_amdgcn_readlane(kk, (T)), (uint32_t)__builtin_amdgcn_readlane(bb, (T))}
-            int t = 0;
-            while (t < n && !W.bad) {
-                if (!primed) {                                          // restart: exact steps up to an even slot, exact loads, refill step, one ordinary step
-                    W.slow = false; ++W.n_restarts;
-                    while (t < n && !W.bad && ((t & 1) || t + 2 > n)) { ++W.n_exact; const LeanDesc D = DG_DESC(t); lean2_exact_step(W, RP, D, rowrec, in_edge, park_u, park_v, t, lane); ++t; }
-                    if (t >= n || W.bad) break;
-                    {
-                        const LeanDesc D0 = DG_DESC(t);
-                        lean2_issue_cell(A, D0, rowrec, rowrec2, (uint32_t)RP * D0.k2, min(W.pu & 0x7FFFu, D0.k2 - 1u), min(W.pv & 0x7FFFu, D0.k2 - 1u), (uint32_t)max(W.r, 0));
-                        W.sel = 0; W.e_prev = 0;
-                        const LeanDesc N1 = DG_DESC(t + 1), N2 = DG_DESC(t + 2);
-                        lean2_step<true>(W, RP, N1, N2, rowrec, rowrec2, park_u, park_v, t, lane, A, B);
-                        if (W.slow) { ++W.n_exact; lean2_exact_step(W, RP, D0, rowrec, in_edge, park_u, park_v, t, lane); ++t; continue; }
-                        ++t;
-                        const LeanDesc M2 = DG_DESC(t + 2);
-                        lean2_step<false>(W, RP, N2, M2, rowrec, rowrec2, park_u, park_v, t, lane, B, A);
-                        if (W.slow) { ++W.n_exact; lean2_exact_step(W, RP, N1, rowrec, in_edge, park_u, park_v, t, lane); ++t; continue; }
-                        ++t;
-                        primed = true;
-                    }
-                    continue;
-                }
-                // fast loop: pairs of steps from an even slot; it stops at a rank above 1 (the slot is then redone by restart()) or at the window's end
-#define DG_L2_STEP(T, X, Y) { const LeanDesc N1 = DG_DESC((T) + 1), N2 = DG_DESC((T) + 2); lean2_step<false>(W, RP, N1, N2, rowrec, rowrec2, park_u, park_v, (T), lane, X, Y); }
-                // unrolled by hand (8 steps per trip): the loop's back edge waits for the loads in flight -- one un-overlapped step per trip
-#define DG_L2(K, X, Y) DG_L2_STEP(t + (K), X, Y); if (W.slow) { t += (K); break; }
-                for (; t + 7 < n; t += 8) {
-                    if (lane == 0 && (t & 8) == 0) DG_PUBLISH(base - t, W.r);
-                    DG_L2(0, A, B) DG_L2(1, B, A) DG_L2(2, A, B) DG_L2(3, B, A) DG_L2(4, A, B) DG_L2(5, B, A) DG_L2(6, A, B) DG_L2(7, B, A)
-                }
-                if (!W.slow)
-                    for (; t + 1 < n; t += 2) { DG_L2(0, A, B) DG_L2(1, B, A) }
-#undef DG_L2
-#undef DG_L2_STEP
-                if (W.slow || t < n) primed = false;                    // a rank above 1, or one slot left in the window: the plain way
-            }
-#undef DG_DESC
-            if (lane < n && !W.bad) path[base - lane] = make_uint2(park_u, park_v);
-        }
-        si = (int)(W.pu & 0x7FFFu); sj = (int)(W.pv & 0x7FFFu);
-        if (W.bad || W.r < 0) value = CHAIN_CORRUPT;
-    }
-    if (lane == 0) { DG_PUBLISH(INT32_MIN, 0); st->i = si; st->j = sj; st->r = W.r; st->value = value; atomicAdd(&sy->n_restarts, W.n_restarts); atomicAdd(&sy->n_exact, W.n_exact); }
-#undef DG_PUBLISH
-}
-#undef DG_RL
-
-// second records: the first two in-edge words of a vertex's first two in-neighbours ({in0(p0), in1(p0), in0(p1), in1(p1)}, all ones
-// where there is no such edge); one thread per vertex, its level by bisection over the level descriptors
-__global__ __launch_bounds__(256) void dp_rowrec2_kernel(const LevelDesc *__restrict__ descs, int L, const uint4 *__restrict__ rowrec, int64_t nV, uint4 *__restrict__ out) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nV) return;
-    int lo = 0, hi = L - 1;                                            // last level whose first vertex is <= v
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int64_t)descs[mid].b0 <= v) lo = mid; else hi = mid - 1; }
-    const uint4 rr = rowrec[v];
-    uint32_t o[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    if (lo >= 1) {
-        const int64_t a0 = descs[lo].a0;
-        const int kprev = descs[lo].k;
-        for (int q = 0; q < 2; ++q) {
-            if ((uint32_t)q >= rr.y) break;
-            const uint32_t w = q ? rr.w : rr.z;
-            const int p = (int)(w & 0x7FFFu);
-            if (p >= kprev) continue;
-            const uint4 pr = rowrec[a0 + p];
-            if (pr.y > 0u) o[2 * q] = pr.z;
-            if (pr.y > 1u) o[2 * q + 1] = pr.w;
-        }
-    }
-    out[v] = make_uint4(o[0], o[1], o[2], o[3]);
-}
-
 // levels in parallel over the whole grid; *out is zeroed by the host before the launch (value is written by block 0)
 __global__ __launch_bounds__(256) void dp_trace_finish_kernel(const LevelDesc *__restrict__ descs, int L, const uint2 *__restrict__ path,
                                                               ColourCsr col, int cap_e, int32_t *__restrict__ edges /* 4*cap_e */,
@@ -606,11 +408,7 @@ void trace_launch_warm_rows(const DpState &S, int lb, int le, hipStream_t s) {  
 }
 
 void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp_biased, const int32_t *final_val, hipStream_t s) {
-    if (S.lean_chain && S.pair_chain)
-        hipLaunchKernelGGL(dp_trace_chain_lean2_kernel, dim3(LEAN_BLOCKS), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
-                           S.d_rowrec.as<uint4>(), S.d_rowrec2.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>(),
-                           (ChainSync *)(S.d_chain.as<char>() + 64), ++S.chain_seq);
-    else if (S.lean_chain)
+    if (S.lean_chain)
         hipLaunchKernelGGL(dp_trace_chain_lean_kernel, dim3(LEAN_BLOCKS), dim3(64), 0, s, S.d_descs.as<LevelDesc>(), l_hi, l_lo, S.RP, S.R, bp_biased, final_val,
                            S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>(),
                            (ChainSync *)(S.d_chain.as<char>() + 64), ++S.chain_seq);
@@ -619,18 +417,10 @@ void trace_launch_chain(const DpState &S, int l_hi, int l_lo, const uint16_t *bp
                            S.d_rowrec.as<uint4>(), S.d_in_edge.as<uint32_t>(), S.d_path.as<uint2>(), S.d_chain.as<ChainState>());
 }
 
-int trace_build_second_records(DpState &S, hipStream_t s) {             // after the row records are on the device (either table route)
-    if (int rc = S.d_rowrec2.ensure(16 * (size_t)S.nV)) return rc;
-    hipLaunchKernelGGL(dp_rowrec2_kernel, dim3((unsigned)((S.nV + 255) / 256)), dim3(256), 0, s, S.d_descs.as<LevelDesc>(), S.L, S.d_rowrec.as<uint4>(), (int64_t)S.nV,
-                       S.d_rowrec2.as<uint4>());
-    DG_HIP(hipGetLastError());
-    return DG_OK;
-}
-
 void trace_debug_report(const DpState &S) {                            // DG_DEBUG: how much of the walk the helpers covered
     ChainSync sy;
     if (hipMemcpy(&sy, S.d_chain.as<char>() + 64, sizeof sy, hipMemcpyDeviceToHost) == hipSuccess)
-        fprintf(stderr, "[dg] chain walk helpers: %d block-launches prefetched %d levels (since load); two-ahead walk: %d restarts, %d exact steps\n", sy.n_helpers, sy.n_levels, sy.n_restarts, sy.n_exact);
+        fprintf(stderr, "[dg] chain walk helpers: %d block-launches prefetched %d levels (since load)\n", sy.n_helpers, sy.n_levels);
 }
 
 void trace_launch_finish(const DpState &S, hipStream_t s) {

@@ -328,6 +328,7 @@ bool Pipeline::build_levelized_fast(ExpandedGraph &g, std::vector<std::vector<An
         if ((int32_t)tail != n0) kahn_rc = 2;                         // cycle: the literal route throws
     };
     std::thread kahn_thread;
+    struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } kahn_guard{kahn_thread};   // an allocation below may throw: never unwind past a joinable thread
     const int NTC = NT > 1 ? NT - 1 : 1;                             // threads of the colour work beside it
     if (NT > 1) kahn_thread = std::thread(kahn); else kahn();
     wait_fit();                                                      // the grid fit has been running beside everything above: homo_bv from here on

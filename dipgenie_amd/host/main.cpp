@@ -77,15 +77,22 @@ static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint6
 static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) {
     dg_ctx *x = ((LazyCtx *)c)->get();
     if (!x) return DG_ERR_NO_DEVICE;
-    // DG_DP_OPTIONS="key=value,key=value": dg_dp_set_option knobs for experiments and the segmented-lattice tests (none needed in normal use)
+    // DG_DP_OPTIONS="key=value,key=value": dg_dp_set_option tuning knobs for profiling and for the segmented-lattice tests (none needed
+    // in normal use).  Honoured with a notice on stderr; the fault-injection keys (test_*) are refused here -- they exist for the
+    // library's own tests, which set them through the C ABI.
     if (const char *o = getenv("DG_DP_OPTIONS")) {
         std::string all(o);
+        if (!all.empty()) fprintf(stderr, "[dg::main] DG_DP_OPTIONS honoured: %s\n", all.c_str());
         for (size_t a = 0; a < all.size();) {
             size_t b = all.find(',', a);
             if (b == std::string::npos) b = all.size();
             const std::string kv = all.substr(a, b - a);
             const size_t eq = kv.find('=');
-            if (eq != std::string::npos && dg_dp_set_option(x, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != DG_OK) return DG_ERR_ARG;
+            if (eq != std::string::npos) {
+                const std::string key = kv.substr(0, eq);
+                if (key.rfind("test_", 0) == 0) { fprintf(stderr, "[E::main] DG_DP_OPTIONS: '%s' is a fault-injection key, refused\n", key.c_str()); return DG_ERR_ARG; }
+                if (dg_dp_set_option(x, key.c_str(), atoll(kv.c_str() + eq + 1)) != DG_OK) return DG_ERR_ARG;
+            }
             a = b + 1;
         }
     }

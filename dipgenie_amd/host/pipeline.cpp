@@ -191,7 +191,7 @@ int Pipeline::compute_and_classify_anchors(std::string &err) {
         fit_n_hom = 0;
         for (int32_t id = 0; id < count_sp_r; ++id) {
             int m = fit_sp_count[id];
-            if (m == 0) continue;
+            if (m <= 0 || m > max_mult) continue;                      // (0: solver.cpp:845; the rest cannot come from the device path, and injected spectra are checked in dgr_inject_spectrum)
             if (label[m] < 0) label[m] = kg_is_hom(P, m) ? 1 : 0;
             homo_bv[id] = (uint8_t)label[m];
             fit_n_hom += label[m];

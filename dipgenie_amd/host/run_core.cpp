@@ -1,19 +1,14 @@
 // libdipgenie_run.so -- the host pipeline behind include/dipgenie_run.h (sharded runs, BASELINE configs[3]).
-// Backend-agnostic: DGR_BACKEND_HIP wires the Backend table to libdipgenie_hip.so (product); the test harness compiles the
-// same file with DGR_BACKEND_ORACLE against oracle/liboracle.so (tests/harness/Makefile) -- never shipped.
+// This file knows no backend: the device loops are reached through the Backend table that dgr_wire_backend() fills
+// (run_backend_hip.cpp: libdipgenie_hip.so, the only backend this package holds; the CPU tests link a checker-side
+// backend of their own from tests/harness/).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
 #include "../../include/dipgenie_run.h"
-#include "pipeline.hpp"
-
-#if defined(DGR_BACKEND_ORACLE)
-#include "../../oracle/oracle.h"
-#elif !defined(DGR_BACKEND_HIP)
-#error "define DGR_BACKEND_HIP (product) or DGR_BACKEND_ORACLE (test harness)"
-#endif
+#include "run_core.hpp"
 
 static_assert(sizeof(dgr_options) == 56 && sizeof(dgr_summary) == 88, "layouts mirrored by dipgenie_amd/run_sharded.py");
 
@@ -21,45 +16,6 @@ namespace {
 thread_local std::string g_err;
 int fail(const std::string &m) { g_err = m; return -1; }
 }  // namespace
-
-struct dgr_handle {
-    dg::Pipeline p;
-    std::string hap_buf;
-    int32_t hap_buf_h = -1;
-    std::string read_bases;
-    std::vector<int64_t> read_off;
-    void *ctx = nullptr;              // dg_ctx (HIP backend)
-    int device = 0;
-};
-
-#if defined(DGR_BACKEND_HIP)
-static int b_sketch_reads(void *c, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **cnt, int64_t *nd) { return dg_sketch_reads((dg_ctx *)c, b, off, n, k, w, h, cnt, nd); }
-static int b_sketch_hap(void *c, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) { return dg_sketch_haplotype((dg_ctx *)c, s, len, k, w, h, p, n); }
-static int b_dp(void *c, const dg_dp_graph *g, dg_dp_result *r) { return dg_dp_solve_diploid((dg_ctx *)c, g, r); }
-static int b_hap(void *c, const dg_hap_graph *g, int32_t *dp, int32_t *bv, int32_t *br) { return dg_dp_solve_haploid((dg_ctx *)c, g, dp, bv, br); }
-static int b_anchor_begin(void *c, int32_t nh, int32_t nv, const int32_t *top, int k, int w) { return dg_anchor_begin((dg_ctx *)c, nh, nv, top, k, w); }
-static int b_anchor_add(void *c, int32_t h, const char *s, int64_t len, const int32_t *sv, const int64_t *ss, int64_t ns, int64_t *n) { return dg_anchor_add_haplotype((dg_ctx *)c, h, s, len, sv, ss, ns, n); }
-static int b_anchor_add_sk(void *c, int32_t h, int64_t len, const uint64_t *hash, const int64_t *pos, int64_t n, const int32_t *sv, const int64_t *ss, int64_t ns) {
-    return dg_anchor_add_haplotype_sketched((dg_ctx *)c, h, len, hash, pos, n, sv, ss, ns);
-}
-static int b_anchor_finish(void *c, const uint64_t *sp, int64_t n, float thr, dg_anchor_result *out) { return dg_anchor_finish((dg_ctx *)c, sp, n, thr, out); }
-static void b_hint(void *c, int64_t est_cells) {
-    const double bytes = 2.0 * (double)est_cells;
-    if (bytes >= 4e9) dg_dp_prealloc((dg_ctx *)c, bytes > 8e18 ? 0 : (int64_t)bytes);
-}
-static const char *b_err() { return dg_last_error(); }
-#else
-static int o_sketch_reads(void *, const char *b, const int64_t *off, int64_t n, int k, int w, uint64_t **h, int32_t **c, int64_t *nd) { return orc_sketch_reads(b, off, n, k, w, h, c, nd); }
-static int o_sketch_hap(void *, const char *s, int64_t len, int k, int w, uint64_t **h, int64_t **p, int64_t *n) {
-    const int64_t cnt = orc_minimizers(s, len, k, w, nullptr, nullptr, 0);
-    *h = (uint64_t *)malloc(sizeof(uint64_t) * (cnt + 1));
-    *p = (int64_t *)malloc(sizeof(int64_t) * (cnt + 1));
-    *n = orc_minimizers(s, len, k, w, *h, *p, cnt);
-    return 0;
-}
-static int o_dp(void *, const dg_dp_graph *g, dg_dp_result *r) { return orc_dp_solve_diploid((const orc_dp_graph *)g, (orc_dp_result *)r, nullptr); }
-static const char *o_err() { return "oracle"; }
-#endif
 
 extern "C" const char *dgr_last_error(void) { return g_err.c_str(); }
 
@@ -81,9 +37,7 @@ extern "C" dgr_handle *dgr_open(const dgr_options *o) {
 
 extern "C" void dgr_close(dgr_handle *H) {
     if (!H) return;
-#if defined(DGR_BACKEND_HIP)
-    if (H->ctx) dg_destroy((dg_ctx *)H->ctx);
-#endif
+    dgr_unwire_backend(H);
     delete H;
 }
 
@@ -121,6 +75,11 @@ extern "C" int dgr_inject_haplotype_sketch(dgr_handle *H, int32_t h, const uint6
 
 extern "C" int dgr_inject_spectrum(dgr_handle *H, const uint64_t *sp_hash, const int32_t *sp_count, int64_t n, const int64_t *hist, int32_t n_bins) {
     if (!H || n < 0 || (n > 0 && (!sp_hash || !sp_count)) || (hist && n_bins < 2)) return fail("dgr_inject_spectrum: bad arguments");
+    // a spectrum entry is a hash held by >= 1 read, keys strictly ascending (solver.cpp:526-546): the counts index the label table later
+    for (int64_t i = 0; i < n; ++i) {
+        if (sp_count[i] < 1) return fail("dgr_inject_spectrum: count < 1 at entry " + std::to_string(i));
+        if (i > 0 && sp_hash[i] <= sp_hash[i - 1]) return fail("dgr_inject_spectrum: hashes not strictly ascending at entry " + std::to_string(i));
+    }
     H->p.inj_sp_hash.assign(sp_hash, sp_hash + n); H->p.inj_sp_count.assign(sp_count, sp_count + n);
     H->p.inj_hist.clear();
     if (hist) H->p.inj_hist.assign(hist, hist + n_bins);
@@ -132,16 +91,8 @@ extern "C" int dgr_solve(dgr_handle *H, dgr_summary *out) {
     if (!H) return fail("dgr_solve: null handle");
     dg::Pipeline &p = H->p;
     if (!p.spectrum_injected && p.opt.reads_file.empty()) return fail("dgr_solve: no reads file and no injected spectrum");
-#if defined(DGR_BACKEND_HIP)
-    if (!H->ctx) H->ctx = dg_create(H->device);
-    if (!H->ctx) return fail(std::string("dgr_solve: ") + dg_last_error());        // no gfx950 device: no CPU fallback
-    p.be.ctx = H->ctx;
-    p.be.sketch_reads = b_sketch_reads; p.be.sketch_haplotype = b_sketch_hap; p.be.dp_solve_diploid = b_dp; p.be.dp_solve_haploid = b_hap;
-    p.be.free_buf = dg_free; p.be.anchor_begin = b_anchor_begin; p.be.anchor_add_haplotype = b_anchor_add; p.be.anchor_finish = b_anchor_finish;
-    p.be.anchor_add_haplotype_sketched = b_anchor_add_sk; p.be.hint_dp_soon = b_hint; p.be.last_error = b_err;
-#else
-    p.be.sketch_reads = o_sketch_reads; p.be.sketch_haplotype = o_sketch_hap; p.be.dp_solve_diploid = o_dp; p.be.free_buf = orc_free; p.be.last_error = o_err;
-#endif
+    std::string werr;
+    if (dgr_wire_backend(H, werr) != 0) return fail("dgr_solve: " + werr);
     const double t0 = dg::now_s();
     std::string err;
     if (p.run_loaded(err) != 0) return fail("dgr_solve: " + err);

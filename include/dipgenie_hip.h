@@ -98,7 +98,7 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   digest 0|1            accumulate the per-level digests
  *   fast 0|1              0: generic sweep kernel only          adaptive_rc 0|1   0: one chunk of all r per task
  *   coop 0|1|2            cooperative fan-in rows off / by cost model / whenever possible
- *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1|2  1: lean chain walk where the lattice allows it, 0: the general one, 2: the two-ahead walk (second row records; slower, parity runs) (next load)
+ *   rowx 0|1              row in-edge matrices (next load)      lean_chain 0|1    1: lean chain walk where the lattice allows it, 0: the general one (next load)
  *   graph_batch n         levels per hipGraph batch (-1: default 1000, 0: plain launches)
  *   l2_prefetch n         levels the per-XCD table prefetcher runs ahead of the sweep (0: off)
  *   pf_far n              levels ahead at which the prefetcher's far blocks pull tables into the Infinity Cache (0: periodic launches instead)
@@ -106,8 +106,6 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
  *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
- *   chain 0|1, chain_rc n, chain_max n   consecutive levels in ONE dispatch with row-completion counters in place of kernel boundaries
- *                         (default 0 = one launch per level: the chained form is correct but 3-6x slower); recombination counts per task (1..4, default 2); levels per dispatch (2..15)
  *   side_stream -1|0|1    L2 prefetcher + score deltas beside the sweep: -1 (default) while this is the only DP state on its device, 0 never, 1 always
  *   test_poison_level l, test_poison_byte b   tests: fill level l of the back-pointer lattice with byte b between sweep and walk (dg_dp_run must answer DG_ERR_STATE)
  *   host_tables 0|1       0 (default): the sweep's tables are built by device kernels from the uploaded graph; 1: on the host, then uploaded (parity twin; next load)

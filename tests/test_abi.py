@@ -42,7 +42,7 @@ def test_run_library_exports_match_header(built_hip):
     lib = rs.RunLib().lib
     for s in syms:
         assert hasattr(lib, s), s
-    assert C.sizeof(rs.RunOptions) == 56 and C.sizeof(rs.RunSummary) == 88   # static_assert-ed in run_lib.cpp
+    assert C.sizeof(rs.RunOptions) == 56 and C.sizeof(rs.RunSummary) == 88   # static_assert-ed in run_core.cpp
     out = subprocess.run(["ldd", rs.RUN_LIB], stdout=subprocess.PIPE).stdout.decode()
     assert "libdipgenie_hip.so" in out and "oracle" not in out
     assert "orc_" not in subprocess.run(["nm", "-D", rs.RUN_LIB], stdout=subprocess.PIPE).stdout.decode()
@@ -64,6 +64,32 @@ def test_product_does_not_link_oracle(built_hip):
         assert "oracle" not in out
         sym = subprocess.run(["nm", "-D", f], stdout=subprocess.PIPE).stdout.decode()
         assert "orc_" not in sym
+
+
+def test_product_sources_do_not_reference_the_checker():
+    """source level: nothing under dipgenie_amd/ includes, imports, links or builds against oracle/ -- the word may appear in comments
+    only (C / C++ / HIP: after //; Python: in docstrings and comments; Makefiles: after #)"""
+    pkg = os.path.join(ROOT, "dipgenie_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            ext = os.path.splitext(f)[1]
+            if ext not in (".cpp", ".hpp", ".hip", ".h", ".py") and f != "Makefile":
+                continue
+            path = os.path.join(dirpath, f)
+            txt = open(path, errors="replace").read()
+            if ext == ".py":
+                code = re.sub(r'"""(.|\n)*?"""', "", txt)
+                code = "\n".join(line.split("#", 1)[0] for line in code.split("\n"))
+            elif f == "Makefile":
+                code = "\n".join(line.split("#", 1)[0] for line in txt.split("\n"))
+            else:
+                code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+                code = "\n".join(line.split("//", 1)[0] for line in code.split("\n"))
+            for n, line in enumerate(code.split("\n"), 1):
+                if re.search(r"oracle|orc_|ORACLE", line):
+                    bad.append(f"{os.path.relpath(path, ROOT)}:{n}: {line.strip()}")
+    assert not bad, "\n".join(bad)
 
 
 def test_cli_usage_and_exit_codes(built_hip, tmp_path):
