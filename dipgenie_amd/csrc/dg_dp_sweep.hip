@@ -590,7 +590,7 @@ __device__ __forceinline__ void sym_gather(const LevelHead &H, const FastArgs &A
                 if (du == 2) relax_select_sym<RC>(vb, dlb, ol | symord_row(1), r0, wb, RP, bval, bord);
             }
         } else {
-            constexpr int U = GENERAL ? (RC >= 4 ? 2 : 4) : (RC >= 8 ? 2 : (RC >= 4 ? 4 : 8));
+            constexpr int U = RC >= 6 ? 1 : (RC >= 3 ? 2 : 4);           // (in-edges per step: U x RC values in flight)
             for (int c0 = GENERAL ? (t_lo & ~63) : 0; c0 < t_hi; c0 += GENERAL ? 64 : (1 << 30)) {
                 const int tb = GENERAL ? max(c0, t_lo) : t_lo, te = GENERAL ? min(c0 + 64, t_hi) : t_hi;
                 if (!rowx) { mypu = 0; if (c0 + lane < te) mypu = A.in_edge[rr.x + c0 + lane]; }
@@ -658,8 +658,9 @@ __device__ __forceinline__ unsigned long long sym_digest(const LevelHead &H, con
 template <int RC, bool DIGEST, bool GENERAL>
 __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
                                                                       int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
-                                                                      FastArgs A, LevelDesc d, int lvl, int n_heavy, const int32_t *__restrict__ heavy_rows) {
+                                                                      FastArgs A, LevelDesc d, int lvl, int n_heavy, const int32_t *__restrict__ heavy_rows, int dbg) {
     __shared__ SymShared<RC> sh;
+    if (dbg & 16) return;
     const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
     publish_level(A.progress, lvl);
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -681,8 +682,13 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
             }
         }
     }
-    // first load round: the block's slot records (the same in every wave of the workgroup)
+    // first load round: the block's slot records (the same in every wave of the workgroup) and the wave's row record
     const uint2 sl = slots_l[g * 64 + lane];
+    int i2;
+    if (heavy_region) { const int h = (int)blockIdx.z; i2 = h < HEAVY_INLINE ? (int)d.heavy_in[h] : heavy_rows[d.heavy_first + h]; }
+    else i2 = tile * SYM_ROWS + wave;
+    const uint4 rr = rowrec_l[min(i2, k2 - 1)];
+    if (dbg & 32) { asm volatile("" ::"v"(sl.x), "v"(rr.x)); return; }
     int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
     const bool act0 = sl.x != 0xFFFFFFFFu;
     const int j2 = act0 ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
@@ -703,10 +709,8 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
     unsigned long long dsum = 0;
     if (heavy_region) {
         // ---- one fan-in row, its in-edges dealt to the SYM_ROWS waves ----
-        const int h = (int)blockIdx.z;
-        const int i2 = h < HEAVY_INLINE ? (int)d.heavy_in[h] : heavy_rows[d.heavy_first + h];
+        if (dbg & 1) return;
         if (cmax < i2) return;                                          // the whole block lies below the diagonal (workgroup-uniform)
-        const uint4 rr = rowrec_l[i2];
         const int du = (int)rr.y;
         uint32_t mypu = 0;
         if (!GENERAL && rowx_stride > 0 && lane < rowx_stride) mypu = rowx_l[i2 * rowx_stride + lane];
@@ -740,13 +744,11 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
     }
     // ---- a tile of SYM_ROWS rows, one wave each ----
     if (cmax < tile * SYM_ROWS) return;                                 // every row of the tile lies beyond the block's last column (workgroup-uniform)
-    const int i2 = tile * SYM_ROWS + wave;
-    const uint4 rr = rowrec_l[min(i2, k2 - 1)];
     const bool row_on = (i2 < k2) & (i2 <= cmax) & !((n_heavy > 0) & ((int)rr.y > COOP_MIN));
     if (row_on) {
         uint32_t mypu = 0;
         if (!GENERAL && rowx_stride > 0 && lane < rowx_stride) mypu = rowx_l[i2 * rowx_stride + lane];
-        sym_gather<RC, GENERAL>(H, A, cur_rsrc, rr, sl, mypu, g, nblk, i2, r0, 0, (int)rr.y, bval, bord);
+        if (!(dbg & 8)) sym_gather<RC, GENERAL>(H, A, cur_rsrc, rr, sl, mypu, g, nblk, i2, r0, 0, (int)rr.y, bval, bord);
         sym_column_max<RC>(steps, j2, bval, bord);
     }
     const unsigned long long hm = __builtin_amdgcn_ballot_w64(head0);
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
         }
     }
     if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+    if (dbg & 4) return;
     __syncthreads();
     // mirror cells (j2, r2, i2): lanes <-> (column of the block, row of the tile), rows fastest: SYM_ROWS consecutive words per column
     const int tt = lane & (SYM_ROWS - 1), c = wave * (64 / SYM_ROWS) + (lane / SYM_ROWS);
@@ -969,8 +972,8 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const uint16_t *dm = dT ? F.delta + d.delta_off - (int64_t)d.in_base * dT : F.delta_zero;
         const int rp_k = S.RP | (d.k << 13);
         const int32_t *hv = S.d_heavy.as<int32_t>();
-#define DG_SYM(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, true>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv); \
-                             else hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, false>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv); } while (0)
+#define DG_SYM(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, true>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg); \
+                             else hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, false>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg); } while (0)
 #define DG_SYM_RC(DG) do { switch (rc) { case 1: DG_SYM(1, DG); break; case 2: DG_SYM(2, DG); break; case 3: DG_SYM(3, DG); break; case 4: DG_SYM(4, DG); break; \
                                          case 6: DG_SYM(6, DG); break; default: DG_SYM(8, DG); break; } } while (0)
         if (S.want_digest) DG_SYM_RC(true); else DG_SYM_RC(false);
