@@ -126,6 +126,7 @@ struct DpState {
     int64_t segment_cells = 0;                          // segment_cells: force lattice segments of at most this many cells (tests)
     int64_t host_threads = 16;                          // host_threads: threads of dg_dp_load_graph's host table construction
     int64_t test_poison_level = 0, test_poison_byte = 0xFF;   // test_poison_*: overwrite one level of the lattice between sweep and walk (tests of the corrupt-lattice path)
+    // (measurement build -DDG_SYM only; the product library has neither the kernels nor the options)
     int64_t use_sym = 1;                                // sym: symmetric form of the sweep on wide levels (1: levels at least sym_min_k2 wide, 2: wherever the form exists, 0: off)
     int64_t sym_dbg = 0;                                // (experiments: 1 no fan-in workgroups, 4 no mirror stores, 8 no gathers, 16 empty kernel, 32 first load round only -- results void)
     int64_t sym_min_k2 = 160, sym_rc = 4;               // sym_min_k2, sym_rc: width from which a level takes the symmetric form; recombination counts per task there (1-4, 6, 8)
@@ -244,6 +245,7 @@ struct SweepLaunch {                     // per-run launch context
 void sweep_prepare(const DpState &S, SweepLaunch &X);
 void sweep_init_state(const DpState &S, hipStream_t s);                  // level 0: every r starts at 0 (:534-535)
 void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s);
+bool sweep_launch_sym(DpState &S, SweepLaunch &X, int l, hipStream_t s);    // measurement build (-DDG_SYM, dg_dp_sweep_sym.hip): the symmetric form, where it applies
 void sweep_warm_tables(const DpState &S, const SweepLaunch &X, int q0, int q1, hipStream_t s);
 int sweep_prefetch_begin(DpState &S, const SweepLaunch &X, int lb, int le, bool delta_resident, hipStream_t s);
 void sweep_prefetch_end(DpState &S, int le, hipStream_t s);

@@ -431,7 +431,11 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
-        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1}, {"sym", &S.use_sym, 0}, {"sym_min_k2", &S.sym_min_k2, 1}, {"sym_rc", &S.sym_rc, 1}, {"sym_dbg", &S.sym_dbg, 0}, {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
+        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1},
+#ifdef DG_SYM
+        {"sym", &S.use_sym, 0}, {"sym_min_k2", &S.sym_min_k2, 1}, {"sym_rc", &S.sym_rc, 1}, {"sym_dbg", &S.sym_dbg, 0},
+#endif
+        {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
     };
     for (auto &o : plain)
         if (!strcmp(key, o.name)) { *o.field = v < o.lo ? o.lo : v; return DG_OK; }

@@ -3,9 +3,9 @@
 # resident) and on the bench workload's graph (synthetic MHC-24).   bash tools/sym_ab.sh [c5_backbone_bp] ["k=v,..." ...]
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-export HIP_FORCE_DEV_KERNARG=1
+export HIP_FORCE_DEV_KERNARG=1 DG_LIB=$PWD/bin/libdipgenie_hip_sym.so   # the measurement build (make -C dipgenie_amd/csrc sym)
 BP=${1:-1000000}; shift || true
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "symmetric or random_levelized or alternative or giant or toy" --timeout 300 > gpurun_out/sym_tests.log 2>&1; tail -3 gpurun_out/sym_tests.log
+timeout -k 10 900 env -u DG_LIB python -m pytest tests/test_gpu_parity.py -x -q -k "symmetric" --timeout 300 > gpurun_out/sym_tests.log 2>&1; tail -3 gpurun_out/sym_tests.log
 grep -q passed gpurun_out/sym_tests.log && ! grep -q failed gpurun_out/sym_tests.log || { grep -B40 Error gpurun_out/sym_tests.log | tail -80; exit 1; }
 D=/tmp/c5ab; mkdir -p $D
 python3 tools/c5_gen.py $BP $D > gpurun_out/sym_gen.log 2>&1

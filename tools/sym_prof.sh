@@ -3,7 +3,7 @@
 #   bash tools/sym_prof.sh <backbone_bp> "k=v,..." ["k=v,..." ...]        -> gpurun_out/sym_prof_<n>.txt
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-export HIP_FORCE_DEV_KERNARG=1
+export HIP_FORCE_DEV_KERNARG=1 DG_LIB=$PWD/bin/libdipgenie_hip_sym.so   # the measurement build (make -C dipgenie_amd/csrc sym)
 BP=${1:-1000000}; shift
 D=/tmp/c5ab; mkdir -p $D
 [ -f $D/c5.dpg ] || { python3 tools/c5_gen.py $BP $D > gpurun_out/sym_gen.log 2>&1; bin/DipGenie -t16 -p2 -R32 -g $D/c5.gfa -r $D/c5.fa -o $D/dump.fa -D $D/c5 -X > /dev/null 2>&1; }
