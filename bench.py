@@ -94,9 +94,9 @@ def _run_reference(exe, cores, gfa, reads, out_fa):
     return max(int(m.group(1)), 1) / 1e3, wall, hashlib.md5(open(out_fa, "rb").read()).hexdigest()
 
 
-def reference_baseline(cache, workload, bench_gfa, device):
+def reference_baseline(cache, workload, bench_gfa, device, frac=0.1):
     """The reference's own OpenMP solver (oracle/_ref/DipGenie_ref, built by __graft_entry__.build() from /root/reference
-    where that exists) timed on this node's host cores on a bounded sample of the bench workload: the first ~1 % of the
+    where that exists) timed on this node's host cores on a bounded sample of the bench workload: the first ~10 % of the
     24-walk panel cut out as a panel of its own (dipgenie_amd.synth.prefix_panel; reads re-simulated with the same
     recipe).  Our CLI solves the same sample on the GPU: the two FASTA files must be identical, and its summary gives
     the cell count.  Falls back to the MHC_4 instance (BASELINE configs[1], golden md5) and then to None (oracle port)."""
@@ -110,7 +110,7 @@ def reference_baseline(cache, workload, bench_gfa, device):
         try:
             from dipgenie_amd import synth
             pre_gfa, pre_fa = os.path.join(cache, "mhc24_prefix.gfa"), os.path.join(cache, "mhc24_prefix.fa")
-            info = synth.prefix_panel(bench_gfa, pre_gfa, pre_fa, 0.01)
+            info = synth.prefix_panel(bench_gfa, pre_gfa, pre_fa, frac)
             r = _run_reference(exe, cores, pre_gfa, pre_fa, os.path.join(cache, "mhc24_prefix_ref.fa"))
             ours_fa, ours_js = os.path.join(cache, "mhc24_prefix_ours.fa"), os.path.join(cache, "mhc24_prefix_ours.json")
             subprocess.run([os.path.join(ROOT, "bin", "DipGenie"), "-t", str(cores), "-p2", "-R18", "-g", pre_gfa, "-r", pre_fa, "-o", ours_fa,
@@ -120,7 +120,7 @@ def reference_baseline(cache, workload, bench_gfa, device):
                 dp_s, wall, md5 = r
                 return {"value": ours["cells"] / dp_s, "unit": "cells/s", "cores": cores, "kind": "reference",
                         "threads_requested": 32, "threads_available": cores,
-                        "sample": f"reference binary -t{cores} -p2 -R18 on the first 1 % of the bench panel cut out as its own panel (24 walks, "
+                        "sample": f"reference binary -t{cores} -p2 -R18 on the first {100 * frac:g} % of the bench panel cut out as its own panel (24 walks, "
                                   f"{info['hap_bp'][0]} bp, {ours['n_levels']} levels, {ours['cells']} cells, {info['n_reads']} reads): its DP function took "
                                   f"{dp_s:.2f} s of {wall:.1f} s end to end; FASTA identical to the GPU run on the same sample (md5 {md5[:8]}). "
                                   f"Threads: {cores} = this box's CPU share (north_star names a 32-thread baseline; no 32-core host is available to this run). "
@@ -189,9 +189,77 @@ def attach_profile(roof, launch_profile, workload):
                               "calibrated FETCH_SIZE of all sweep launches of one DP pass, separate --pmc passes, plain launches (sync_every)")
     roof["avg_launch_ms_rocprof"] = prof["kernel_trace"]["avg_launch_ns"] / 1e6
     roof["frac_rocprof"] = roof["algorithmic_bytes_per_launch"] / prof["kernel_trace"]["avg_launch_ns"] / roof["peak"]
+    roof["frac_rocprof_note"] = ("an UNDER-TRACER figure, not a second estimate of the untraced rate: every traced dispatch carries its own completion signal and "
+                                 "timestamps, so the traced durations sum to more than this run's whole step; `frac` (HIP events over the untraced launches) is the rate")
     # what the chip really moves per second during the sweep (counter bytes over THIS run's HIP-event launch time) against the HBM peak
     lo, hi = roof["traffic_range"]
     roof["hbm_frac_measured"] = [lo / (roof["avg_launch_ms"] * 1e-3) / 1e9 / roof["peak"], hi / (roof["avg_launch_ms"] * 1e-3) / 1e9 / roof["peak"]]
+
+
+def native_runtime_check(dpg, device, warm, passes):
+    """the DP part of the timed steps again, from plain C++ over the C ABI (bin/dg_dp_bench): a process that runs libdipgenie_hip.so on the
+    HIP runtime it was built against (this process imported torch first and runs it on torch's bundled runtime)"""
+    exe = os.path.join(ROOT, "bin", "dg_dp_bench")
+    try:
+        p = subprocess.run([exe, dpg, str(warm), str(passes), str(device)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        return json.loads(p.stdout.decode().strip().split("\n")[-1]) if p.returncode == 0 else {"error": p.stderr.decode()[-300:]}
+    except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+        return {"error": repr(e)}
+
+
+def config5_block(cache, device, cores):
+    """BASELINE configs[4] at a tenth of its size (5 Mbp backbone x 100 walks, seed 22, -p2 -R32, 4x reads): the tier where the
+    back-pointer lattice (1.4 TB) does not fit HBM, so the drop-in CLI runs checkpoint + recompute exactly as at full size.  One run
+    of bin/DipGenie as a child process (about 11 s); the value pass (levels swept once, values only) gives cells/s, the second pass
+    (every segment re-swept with back-pointers and walked) the recompute factor.  Counter bytes come from the newest committed
+    profiles/rNN_c5_roofline.json (tools/c5_profile.sh + tools/c5_roofline.py), used only if it was taken on the same launches."""
+    import glob
+    from dipgenie_amd import synth
+    d = os.path.join(cache, "c5_5m")
+    os.makedirs(d, exist_ok=True)
+    gfa, fa = os.path.join(d, "c5.gfa"), os.path.join(d, "c5.fa")
+    if not (os.path.exists(gfa) and os.path.exists(fa)):
+        segs, links, walks, reads = synth.linear_panel(22, backbone_bp=5_000_000, n_haps=100)
+        synth.write_gfa(gfa + ".tmp", segs, links, walks); synth.write_fasta(fa + ".tmp", reads)
+        os.replace(gfa + ".tmp", gfa); os.replace(fa + ".tmp", fa)
+        del segs, links, walks, reads
+    js = os.path.join(d, "o.json")
+    t0 = time.time()
+    p = subprocess.run([os.path.join(ROOT, "bin", "DipGenie"), "-t", str(cores), "-p2", "-R32", "-g", gfa, "-r", fa, "-o", os.path.join(d, "o.fa"), "-J", js, "-G", str(device)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    wall = time.time() - t0
+    if p.returncode != 0:
+        return {"error": p.stderr.decode()[-300:]}
+    sm = json.load(open(js))
+    cells, fwd_s, tb_s = sm["cells"], sm["dp_forward_ms"] / 1e3, sm["dp_traceback_ms"] / 1e3
+    alg = 32.0 * cells + 16.0 * sm["dp_edge_pairs"] + 4.0 * sm["dp_colour_entries"]          # SURVEY.md s8d, one pass
+    achieved = alg / fwd_s / 1e9
+    blk = {"workload": "chr22-style panel, 5 Mbp backbone x 100 walks (seed 22), -p2 -R32, 4x reads: BASELINE configs[4] at a tenth of its size; lattice beyond HBM "
+                       "(checkpoint + recompute, nothing forced)", "cells": cells, "levels": sm["n_levels"], "vertices": sm["n_vertices"], "dp_value": sm["dp_value"],
+           "lattice_segments": sm["dp_segments"], "lattice_chunks": sm["dp_chunks"],
+           "value_pass_cells_per_s": cells / fwd_s, "value_pass_s": fwd_s, "recompute_and_walk_s": tb_s, "recompute_factor": (fwd_s + tb_s) / fwd_s,
+           "dp_cells_per_s_both_passes": cells / (fwd_s + tb_s), "end_to_end_s": wall, "stages_s": sm.get("stages"),
+           "roofline": {"bound": "hbm", "kernel": "dp_sweep_fast_kernel / dp_sweep_coop_kernel (value pass)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_pass": alg, "launches_both_passes": sm["dp_forward_launches"],
+                        "avg_launch_ms_value_pass": 1e3 * fwd_s / max(sm["n_levels"] - 1, 1), "traffic": None,
+                        "note": "frac prices the s8d bytes (16-byte cells) against the value pass; the chip moves 4-byte values (+ 2-byte back-pointers in the second pass): see traffic"}}
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_c5_roofline.json")))
+    if found:
+        prof = json.load(open(found[-1]))
+        name = os.path.relpath(found[-1], ROOT)
+        if prof.get("cells") == cells and prof["kernel_trace"]["sweep_launches"] == sm["dp_forward_launches"]:
+            lo, hi = prof["traffic_bytes_one_run"]
+            r = blk["roofline"]
+            r["traffic"] = hi
+            r["traffic_unit"] = "bytes per CLI run (both passes, all sweep launches)"
+            r["traffic_range"] = [lo, hi]
+            r["traffic_source"] = (f"{name} (committed, not measured in this run; same cells and sweep launch count): WRITE_SIZE + FETCH_SIZE x 1.5-2.0, separate --pmc passes; "
+                                   "these counters sit on the L2s' fabric side and include Infinity-Cache hits: an upper bound of HBM traffic")
+            r["fabric_frac_measured"] = [lo / (fwd_s + tb_s) / 1e9 / HBM_PEAK_GBS, hi / (fwd_s + tb_s) / 1e9 / HBM_PEAK_GBS]
+            r["avg_launch_us_under_tracer"] = prof["kernel_trace"]["avg_launch_us_under_tracer"]
+        else:
+            blk["roofline"]["traffic_note"] = f"{name} was taken on another set of launches: ignored"
+    return blk
 
 
 def main():
@@ -208,6 +276,8 @@ def main():
     ap.add_argument("--e2e-runs", type=int, default=3, help="timed end-to-end CLI runs (the median is reported)")
     ap.add_argument("--e2e-gap-s", type=float, default=5.0, help="pause between CLI runs: the driver releases an exited run's HBM in the background")
     ap.add_argument("--no-config4", action="store_true", help="N = 1 only: skip the 30x read-set scoring measurement (BASELINE configs[3])")
+    ap.add_argument("--no-config5", action="store_true", help="N = 1 only: skip the 5 Mbp x 100-walk run of the CLI (BASELINE configs[4] at a tenth of its size, about 25 s)")
+    ap.add_argument("--ref-sample-frac", type=float, default=0.1, help="prefix of the bench panel the reference binary is timed on (cpu_baseline)")
     args = ap.parse_args()
 
     import torch
@@ -497,13 +567,31 @@ def main():
             port = {"value": ref["cells"] / dt, "unit": "cells/s", "cores": 1, "kind": "port",
                     "sample": f"first {P} of {g.n_levels} levels of the same graph ({ref['cells']} cells, {dt:.1f} s, "
                               "oracle/oracle_dp.cpp single thread; result cross-checked against the GPU)"}
-            refb = None if args.no_reference_baseline else reference_baseline(args.cache, args.workload, gfa, local_rank)
+            refb = None if args.no_reference_baseline else reference_baseline(args.cache, args.workload, gfa, local_rank, args.ref_sample_frac)
             line["cpu_baseline"] = refb or port
             if refb:
                 line["cpu_baseline_port"] = port
-        print(json.dumps(line), flush=True)
     ctx.close()
     ctx_sk.close()
+    if rank == 0:
+        if world == 1:
+            # the remaining two blocks run as child processes on the system's HIP runtime, after this process has released its device memory
+            del ctx, ctx_sk
+            torch.cuda.empty_cache()
+            time.sleep(args.e2e_gap_s)
+            nat = native_runtime_check(pre + ".dpg", local_rank, args.warmup, args.steps)
+            if "cells_per_s" in nat:
+                nat["vs_this_process_dp_only"] = nat["cells_per_s"] / (cells * steps / acc["dp"])
+                nat["note"] = ("bin/dg_dp_bench: the DP passes of the timed steps again from plain C++ over the C ABI, in a process bound to the HIP runtime the library "
+                               "was built against; compare cells_per_s with cells x steps / dp wall of this process")
+            if "hip_runtime" in line:
+                line["hip_runtime"]["native_runtime_check"] = nat
+            else:
+                line["native_runtime_check"] = nat
+            if not args.no_config5:
+                time.sleep(args.e2e_gap_s)
+                line["config5"] = config5_block(args.cache, local_rank, usable_cores())
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

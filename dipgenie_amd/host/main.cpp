@@ -213,11 +213,12 @@ int main(int argc, char **argv) {
         if (f) {
             fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "
                        "\"spectrum\": %lld, \"n_levels\": %lld, \"n_vertices\": %lld, \"cells\": %llu, \"relaxations\": %llu, "
-                       "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"dp_segments\": %d, \"dp_chunks\": %d, \"dp_forward_ms\": %.3f, \"dp_traceback_ms\": %.3f, \"stages\": {",
+                       "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"dp_segments\": %d, \"dp_chunks\": %d, \"dp_forward_ms\": %.3f, \"dp_traceback_ms\": %.3f, \"dp_forward_launches\": %lld, \"dp_edge_pairs\": %llu, \"dp_colour_entries\": %llu, \"stages\": {",
                     p.sum.dp_value, p.sum.s_het, p.sum.r1, p.sum.r2, p.sum.obj, (long long)p.sum.len1, (long long)p.sum.len2,
                     (long long)p.sum.spectrum, (long long)p.sum.n_levels, (long long)p.sum.n_vertices,
                     (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll,
-                    have_tm ? tm.n_segments : 0, have_tm ? tm.n_chunks : 0, have_tm ? tm.forward_ms : 0.f, have_tm ? tm.traceback_ms : 0.f);
+                    have_tm ? tm.n_segments : 0, have_tm ? tm.n_chunks : 0, have_tm ? tm.forward_ms : 0.f, have_tm ? tm.traceback_ms : 0.f,
+                    have_tm ? (long long)tm.n_forward_launches : 0LL, have_tm ? (unsigned long long)tm.edge_pairs : 0ULL, have_tm ? (unsigned long long)tm.colour_entries : 0ULL);
             for (size_t i = 0; i < p.sum.stage_s.size(); ++i)
                 fprintf(f, "%s\"%s\": %.6f", i ? ", " : "", p.sum.stage_s[i].first.c_str(), p.sum.stage_s[i].second);
             fprintf(f, "}}\n");
