@@ -114,3 +114,13 @@ def test_cli_fails_loudly_without_gpu(built_hip, tmp_path):
                         "-r", os.path.join(ROOT, "tests", "data", "read.fa"), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"no CPU fallback" in p.stderr
     assert not out.exists() or out.stat().st_size == 0
+
+
+def test_integration_md_shows_the_tested_patch():
+    """INTEGRATION.md s2.0-2.3 print the code blocks of oracle/ref_hip_patch.py verbatim (the patch that tests/test_gpu_ref_hip.py
+    proves on the MI355X with the reference's own host code)"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "oracle", "ref_hip_patch.py")).read()
+    for name in ("CTX_DEF", "DP_CALL", "SKETCH_READS", "SKETCH_HAP"):
+        blk = re.search(name + r" = r\'\'\'\n(.*?)\'\'\'", src, flags=re.S).group(1).rstrip("\n")
+        assert blk in doc, name
