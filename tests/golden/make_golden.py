@@ -222,6 +222,67 @@ def anchors(cases):
     return out
 
 
+def io_corners(cases):
+    """GFA / read-file corners of the ingestion stage, goldens from the reference binary:
+    * gfa_flipped_walk: bub_a with its SECOND walk written back to front, every step '<' -- gfa_walk_flip (gfa-io.cpp:64-93) turns it
+      round (the segments' strands are fixed by the first walk that touches them), so the answer is bub_a's;
+    * gfa_reverse_step: one step of one walk reversed ('<' in a forward walk): the walk keeps its majority strand, Solver::read_gfa
+      meets a reverse-strand vertex and the program exits 1 without a FASTA (solver.cpp:116-119);
+    * reads as multi-line FASTA (37 columns), as FASTQ with sequence and quality wrapped over several lines, with CRLF line ends, and
+      with N bases (scattered, runs, one read of N only): kseq.h semantics, hashing of non-ACGT k-mers (solver.cpp:309-313)."""
+    import random
+    ed = os.path.join(HERE, "e2e")
+    src = open(os.path.join(ed, "bub_a.gfa")).read().split("\n")
+    S = [l for l in src if l.startswith("S\t")]; L = [l for l in src if l.startswith("L\t")]
+    W = [l for l in src if l.startswith("W\t")]; H = [l for l in src if l.startswith("H")]
+    w1 = W[1].split("\t")
+    steps = re.findall(r"[<>][^<>]+", w1[6])
+    assert all(st[0] == ">" for st in steps)
+    w1[6] = "".join("<" + st[1:] for st in reversed(steps))
+    open(os.path.join(ed, "gfa_flipped_walk.gfa"), "w").write("\n".join(H + S + L + [W[0], "\t".join(w1)] + W[2:]) + "\n")
+    w2 = W[2].split("\t")
+    st2 = re.findall(r"[<>][^<>]+", w2[6])
+    st2[len(st2) // 2] = "<" + st2[len(st2) // 2][1:]
+    w2[6] = "".join(st2)
+    open(os.path.join(ed, "gfa_reverse_step.gfa"), "w").write("\n".join(H + S + L + W[:2] + ["\t".join(w2)] + W[3:]) + "\n")
+    recs = [r.split("\n", 1) for r in open(os.path.join(ed, "bub_a.fa")).read().split(">")[1:]]
+    recs = [(n.strip(), q.replace("\n", "")) for n, q in recs]
+    wrap = lambda q, w: "\n".join(q[i:i + w] for i in range(0, len(q), w))
+    open(os.path.join(ed, "reads_multiline.fa"), "w").write("".join(f">{n}\n{wrap(q, 37)}\n" for n, q in recs))
+    open(os.path.join(ed, "reads_wrapped.fq"), "w").write("".join(f"@{n}\n{wrap(q, 41)}\n+\n{wrap('I' * len(q), 41)}\n" for n, q in recs))
+    open(os.path.join(ed, "reads_crlf.fa"), "wb").write("".join(f">{n}\r\n{q}\r\n" for n, q in recs).encode())
+    rnd = random.Random(11)
+    withn = []
+    for i, (n, q) in enumerate(recs):
+        q = list(q)
+        if i % 7 == 0:
+            for _ in range(3):
+                q[rnd.randrange(len(q))] = "N"
+        if i % 31 == 5:
+            a = rnd.randrange(len(q) - 12)
+            q[a:a + 12] = "N" * 12
+        if i == 3:
+            q = ["N"] * len(q)
+        withn.append((n, "".join(q)))
+    open(os.path.join(ed, "reads_with_N.fa"), "w").write("".join(f">{n}\n{q}\n" for n, q in withn))
+    base = dict(cases["bub_a"])
+    args = base["args"]
+    for name, gfa, reads in (("gfa_flipped_walk", "gfa_flipped_walk.gfa", "bub_a.fa"), ("reads_multiline", "bub_a.gfa", "reads_multiline.fa"),
+                             ("reads_wrapped_fastq", "bub_a.gfa", "reads_wrapped.fq"), ("reads_crlf", "bub_a.gfa", "reads_crlf.fa"),
+                             ("reads_with_N", "bub_a.gfa", "reads_with_N.fa"), ("reads_with_N_p1", "bub_a.gfa", "reads_with_N.fa")):
+        a = [x if x != "-p2" else "-p1" for x in args] if name.endswith("_p1") else args
+        cases[name] = dict(gfa=f"tests/golden/e2e/{gfa}", reads=f"tests/golden/e2e/{reads}", **run_ref(os.path.join(ed, gfa), os.path.join(ed, reads), a))
+        print(name, cases[name].get("dp_value"), cases[name]["fasta_md5"], flush=True)
+    with tempfile.TemporaryDirectory() as td:                      # the run that must fail
+        out = os.path.join(td, "o.fa")
+        p = subprocess.run([BIN, "-t2"] + args + ["-g", os.path.join(ed, "gfa_reverse_step.gfa"), "-r", os.path.join(ed, "bub_a.fa"), "-o", out],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        cases["gfa_reverse_step"] = dict(gfa="tests/golden/e2e/gfa_reverse_step.gfa", reads="tests/golden/e2e/bub_a.fa", args=args, exit_code=p.returncode,
+                                         fasta_written=os.path.exists(out) and os.path.getsize(out) > 0)
+        print("gfa_reverse_step exit", p.returncode, "fasta written:", cases["gfa_reverse_step"]["fasta_written"], flush=True)
+    assert cases["gfa_flipped_walk"]["fasta_md5"] == cases["bub_a"]["fasta_md5"], "a flipped walk must give bub_a's answer"
+
+
 def dpg():
     """toy levelized DP graphs (dg_dp_graph dumps, what dg_dp_load_graph receives) of the two toy runs: written by the host
     pipeline behind the oracle backend (tests/harness/dg_host_oracle -X -D); the DP values they must give (8 and 14) are
@@ -241,6 +302,10 @@ if __name__ == "__main__":
         json.dump(kat_sketch(), open(os.path.join(HERE, "kat_sketch.json"), "w"), indent=0)
     if "e2e" in what:
         json.dump(e2e(), open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+    if "io" in what:                                              # adds the ingestion corner cases to the existing e2e.json
+        cases = json.load(open(os.path.join(HERE, "e2e.json")))
+        io_corners(cases)
+        json.dump(cases, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
     if "anchors" in what:
         json.dump(anchors(json.load(open(os.path.join(HERE, "e2e.json")))), open(os.path.join(HERE, "anchors.json"), "w"), indent=0)
     if "dpg" in what:

@@ -617,7 +617,18 @@ def _run_cli(cli, case, tmp_path, extra=()):
     return open(out, "rb").read(), json.load(open(js))
 
 
-@pytest.mark.parametrize("name", [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<")])
+def test_cli_reverse_strand_step_exits_1_without_fasta(built_hip, gpu_ctx, tmp_path):
+    """a '<' step inside a forward walk: the reference leaves through exit(1) at solver.cpp:116-119 and writes no FASTA (golden: the
+    reference binary's own behaviour, tests/golden/e2e.json gfa_reverse_step); so does the drop-in CLI"""
+    c = CASES["gfa_reverse_step"]
+    assert c["exit_code"] == 1 and not c["fasta_written"]
+    out = tmp_path / "o.fa"
+    p = subprocess.run([built_hip, "-t4"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert p.returncode == 1 and (not out.exists() or out.stat().st_size == 0)
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<") and "exit_code" not in c])
 def test_cli_e2e_small(built_hip, gpu_ctx, name, tmp_path):
     fa, summ = _run_cli(built_hip, CASES[name], tmp_path)
     assert hashlib.md5(fa).hexdigest() == CASES[name]["fasta_md5"]

@@ -11,7 +11,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CASES = json.load(open(os.path.join(HERE, "golden", "e2e.json")))
-FAST = [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<")]
+FAST = [n for n, c in CASES.items() if not c.get("slow") and not c["gfa"].startswith("<") and "exit_code" not in c]
 
 
 def run_case(binary, case, tmp_path, extra=()):
@@ -37,6 +37,22 @@ def check(case, fa, summ):
 def test_e2e_fast(name, built_cpu, tmp_path):
     fa, summ = run_case(built_cpu, CASES[name], tmp_path)
     check(CASES[name], fa, summ)
+
+
+def test_reverse_strand_step_exits_1_without_fasta(built_cpu, tmp_path):
+    """a '<' step inside a forward walk (the walk keeps its majority strand, gfa-io.cpp:64-93): the reference leaves through exit(1) at
+    solver.cpp:116-119 without writing a FASTA (tests/golden/e2e.json gfa_reverse_step = the reference binary's own behaviour)"""
+    c = CASES["gfa_reverse_step"]
+    assert c["exit_code"] == 1 and not c["fasta_written"]
+    out = tmp_path / "o.fa"
+    p = subprocess.run([built_cpu, "-q", "-t2"] + c["args"] + ["-g", os.path.join(ROOT, c["gfa"]), "-r", os.path.join(ROOT, c["reads"]), "-o", str(out)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert p.returncode == 1 and (not out.exists() or out.stat().st_size == 0)
+
+
+def test_flipped_walk_gives_the_forward_panel_answer():
+    """a walk written back to front with every step '<' is turned round by gfa_walk_flip: the reference's answer on it is bub_a's"""
+    assert CASES["gfa_flipped_walk"]["fasta_md5"] == CASES["bub_a"]["fasta_md5"] and CASES["gfa_flipped_walk"]["dp_value"] == CASES["bub_a"]["dp_value"]
 
 
 @pytest.mark.parametrize("name", ["toy2_p2", "bub_e", "bub_c_p1"])
