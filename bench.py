@@ -207,6 +207,47 @@ def native_runtime_check(dpg, device, warm, passes):
         return {"error": repr(e)}
 
 
+def config4_one_run_block(cache, gfa, device, cores):
+    """BASELINE configs[3] as ONE job: python -m dipgenie_amd.run_sharded (one process per GPU under torch.distributed; here one rank with
+    RCCL and the collective path forced) on the 30x read set written out as a FASTA, beside bin/DipGenie on the same file: what the
+    Python / torch launcher costs on top of the C++ CLI.  Both FASTA files must be identical."""
+    import hashlib
+    from dipgenie_amd import synth
+    arr = np.load(synth.ensure_mhc24_reads(os.path.join(cache, "mhc24")), mmap_mode="r")
+    d = os.path.join(cache, "c4run")
+    os.makedirs(d, exist_ok=True)
+    reads30 = os.path.join(d, "reads30.fa")
+    if not os.path.exists(reads30):
+        n, rl = arr.shape
+        block = np.empty((n, 3 + rl + 1), np.uint8)
+        block[:, :3] = np.frombuffer(b">r\n", np.uint8); block[:, 3:3 + rl] = arr; block[:, -1] = ord("\n")
+        with open(reads30 + ".tmp", "wb") as f:
+            f.write(block.tobytes())
+        os.replace(reads30 + ".tmp", reads30)
+    out = {"reads": int(arr.shape[0]), "read_file": "the 30x read set (seed 30) as a FASTA"}
+    t0 = time.time()
+    p = subprocess.run([os.path.join(ROOT, "bin", "DipGenie"), "-t", str(cores), "-p2", "-R18", "-g", gfa, "-r", reads30, "-o", os.path.join(d, "cli.fa"), "-G", str(device)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    out["cli_wall_s"] = time.time() - t0
+    if p.returncode != 0:
+        return {"error": "CLI: " + p.stderr.decode()[-300:]}
+    time.sleep(5.0)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "dipgenie_amd.run_sharded", "--gpus", "1", "--force-collectives", "--backend", "nccl", "--device", str(device), "-g", gfa, "-r", reads30,
+                        "-o", os.path.join(d, "sharded.fa"), "-J", os.path.join(d, "sharded.json"), "-t", str(cores), "-R", "18", "-q"], env=env, cwd=ROOT,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    out["run_sharded_wall_s"] = time.time() - t0
+    if p.returncode != 0:
+        return {"error": "run_sharded: " + p.stderr.decode()[-300:]}
+    sm = json.load(open(os.path.join(d, "sharded.json")))
+    md5 = lambda f: hashlib.md5(open(f, "rb").read()).hexdigest()
+    out.update(run_sharded_inside_s=sm["wall_s"], run_sharded_stages_s=sm["stages_s"], fasta_identical=md5(os.path.join(d, "cli.fa")) == md5(os.path.join(d, "sharded.fa")),
+               note="run_sharded_wall_s - run_sharded_inside_s = interpreter + torch import + process-group start-up of the launcher; one rank, RCCL, collective path forced "
+                    "(N > 1 under RCCL has never run: one GPU per lease)")
+    return out
+
+
 def config5_block(cache, device, cores):
     """BASELINE configs[4] at a tenth of its size (5 Mbp backbone x 100 walks, seed 22, -p2 -R32, 4x reads): the tier where the
     back-pointer lattice (1.4 TB) does not fit HBM, so the drop-in CLI runs checkpoint + recompute exactly as at full size.  One run
@@ -588,6 +629,9 @@ def main():
                 line["hip_runtime"]["native_runtime_check"] = nat
             else:
                 line["native_runtime_check"] = nat
+            if args.workload == "mhc24" and not args.no_config4:
+                time.sleep(args.e2e_gap_s)
+                line["config4_one_run"] = config4_one_run_block(args.cache, gfa, local_rank, usable_cores())
             if not args.no_config5:
                 time.sleep(args.e2e_gap_s)
                 line["config5"] = config5_block(args.cache, local_rank, usable_cores())

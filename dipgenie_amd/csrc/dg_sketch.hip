@@ -1010,6 +1010,13 @@ extern "C" int dg_sketch_merge_runs_dev(dg_ctx *c, const uint64_t *hash_dev, con
     unsigned long long nd = 0;
     DG_HIP(hipMemcpyAsync(&nd, S.d_n.p, 8, hipMemcpyDeviceToHost, s));
     DG_HIP(hipStreamSynchronize(s));
+    if (nd > 0) {                                          // padding of a fixed-size exchange: (0xFFFF...F, 0) entries collapse into one last entry of count 0
+        unsigned long long last_h = 0; int32_t last_c = 1;
+        DG_HIP(hipMemcpyAsync(&last_h, S.d_uniq.as<uint64_t>() + (nd - 1), 8, hipMemcpyDeviceToHost, s));
+        DG_HIP(hipMemcpyAsync(&last_c, S.d_cnt.as<int32_t>() + (nd - 1), 4, hipMemcpyDeviceToHost, s));
+        DG_HIP(hipStreamSynchronize(s));
+        if (last_h == ~0ULL && last_c == 0) --nd;
+    }
     if ((int64_t)nd > cap) { set_error("merge: %llu distinct exceed capacity %lld", nd, (long long)cap); return DG_ERR_ARG; }
     DG_HIP(hipMemcpyAsync(out_hash_dev, S.d_uniq.p, 8 * (size_t)nd, hipMemcpyDeviceToDevice, s));
     DG_HIP(hipMemcpyAsync(out_count_dev, S.d_cnt.p, 4 * (size_t)nd, hipMemcpyDeviceToDevice, s));

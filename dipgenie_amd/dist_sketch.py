@@ -97,17 +97,35 @@ class HipOps:
         self.capi._check(self.capi.lib.dg_sketch_histogram_dev(self.ctx.h, c.data_ptr(), c.numel(), hist.numel(), hist.data_ptr()), "dg_sketch_histogram_dev")
 
 
-@dataclass
 class Score:
-    """what the scoring stage hands to the DP stage, identical on every rank except the sharded range"""
-    counts: torch.Tensor        # int32 [M]  #reads containing dictionary hash i (kmer_count restricted to D)
-    ids: torch.Tensor           # int64 [M]  global Sp_R id of dictionary hash i, -1 if no read has it
-    n_distinct: int             # count_sp_r: distinct read-minimizer hashes over all reads
-    hist: torch.Tensor          # int64 [HIST_BINS]  Hist_kmer: multiplicity -> #distinct hashes
-    range_hash: torch.Tensor    # int64 [n_r]  this rank's hash range of the global spectrum, sorted
-    range_count: torch.Tensor   # int32 [n_r]
-    range_base: int             # global id of range_hash[0]
-    range_sizes: list           # n_r of every rank
+    """what the scoring stage hands to the DP stage, identical on every rank except the sharded range.  The sizes live on the device
+    (sizes_t); n_distinct / range_base / range_sizes / exchange_overflow read them on first use -- outside the scoring step."""
+
+    def __init__(self, counts, ids, hist, range_hash, range_count, rank, sizes_t=None, sizes=None, overflow_t=None):
+        self.counts = counts            # int32 [M]  #reads containing dictionary hash i (kmer_count restricted to D)
+        self.ids = ids                  # int64 [M]  global Sp_R id of dictionary hash i, -1 if no read has it
+        self.hist = hist                # int64 [HIST_BINS]  Hist_kmer: multiplicity -> #distinct hashes
+        self.range_hash = range_hash    # int64 [n_r]  this rank's hash range of the global spectrum, sorted
+        self.range_count = range_count  # int32 [n_r]
+        self._rank, self._sizes_t, self._sizes, self._overflow_t = rank, sizes_t, sizes, overflow_t
+
+    @property
+    def range_sizes(self):              # n_r of every rank
+        if self._sizes is None:
+            self._sizes = [int(x) for x in self._sizes_t.cpu().tolist()]
+        return self._sizes
+
+    @property
+    def n_distinct(self):               # count_sp_r: distinct read-minimizer hashes over all reads
+        return int(sum(self.range_sizes))
+
+    @property
+    def range_base(self):               # global id of range_hash[0]
+        return int(sum(self.range_sizes[: self._rank]))
+
+    @property
+    def exchange_overflow(self):        # a rank had more pairs for one owner than the fixed-size exchange carries: the step must be repeated (ShardedSketch.validated)
+        return bool(self._overflow_t is not None and int(self._overflow_t.item()) != 0)
 
 
 class ShardedSketch:
@@ -122,6 +140,11 @@ class ShardedSketch:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.gloo = dist.is_initialized() and dist.get_backend() == "gloo"
         self.stream = getattr(ops, "stream", None)
+        # Fixed-size exchange: the first step of a read set exchanges exact runs (all-gather of the world x world send counts + host read
+        # + all-to-all with uneven splits) and fixes `cap` = pairs per (sender, owner) slot, the same on every rank because every rank
+        # sees the same matrix; later steps send [world, 1 + cap, 2] blocks with the run length in row 0 -- no size exchange, no host read.
+        self.cap = None
+        self.pad_slack = 1.25
 
     # gloo (CPU tests, one-GPU rehearsals) moves data through host tensors; RCCL works on the device tensors
     def _c(self, t):
@@ -177,8 +200,7 @@ class ShardedSketch:
             counts = ops.count_rank_dictionary(dict_t, h, c, tail[HIST_BINS:])
             ops.histogram(c, tail[:HIST_BINS])
             self._lap("count + rank dictionary, histogram")
-            n = int(h.numel())
-            return Score(counts=counts, ids=tail[HIST_BINS:] - 1, n_distinct=n, hist=tail[:HIST_BINS], range_hash=h, range_count=c, range_base=0, range_sizes=[n])
+            return Score(counts, tail[HIST_BINS:] - 1, tail[:HIST_BINS], h, c, 0, sizes=[int(h.numel())])
         counts = ops.count_dictionary(dict_t, h, c)
         self._lap("count_dictionary")
         work = None
@@ -186,15 +208,43 @@ class ShardedSketch:
             counts_c = self._c(counts)
             work = dist.all_reduce(counts_c, op=dist.ReduceOp.SUM, async_op=True)
             self._lap("all_reduce counts (issue)")
+        overflow = None
         if not multi:
             rh, rc = h, c
-        else:                                            # (2) hash-range exchange
+        elif self.cap is not None:                       # (2) hash-range exchange, fixed-size blocks: nothing read by the host
+            split = ops.partition(h, W)
+            self._lap("partition")
+            cap, n = self.cap, h.numel()
+            seg = split[1:] - split[:-1]                                             # pairs for every owner
+            col = torch.arange(cap, device=self.device)
+            valid = col[None, :] < seg[:, None]
+            src = (split[:-1, None] + col[None, :]).clamp_(max=max(n - 1, 0))
+            block = torch.empty((W, cap + 1, 2), dtype=torch.int64, device=self.device)
+            block[:, 0, 0] = torch.where(seg <= cap, seg, torch.full_like(seg, -1))   # -1: this run does not fit (see Score.exchange_overflow)
+            block[:, 0, 1] = 0
+            if n > 0:
+                block[:, 1:, 0] = torch.where(valid, h[src], torch.full((1, 1), -1, dtype=torch.int64, device=self.device))   # padding: hash 0xFFFF...F,
+                block[:, 1:, 1] = torch.where(valid, c[src].to(torch.int64), torch.zeros((1, 1), dtype=torch.int64, device=self.device))   # count 0
+            else:
+                block[:, 1:, 0] = -1; block[:, 1:, 1] = 0
+            block = self._c(block)
+            recv = torch.empty_like(block)
+            self._lap("pack payload")
+            dist.all_to_all_single(recv, block)                                      # equal splits: [1 + cap, 2] from every rank
+            recv = self._back(recv)
+            self._lap("all_to_all")
+            overflow = (recv[:, 0, 0] < 0).any().to(torch.int64)
+            body = recv[:, 1:, :].reshape(-1, 2)
+            rh, rc = ops.merge_runs(body[:, 0].contiguous(), body[:, 1].to(torch.int32).contiguous())   # the padding sorts last and is dropped there
+            self._lap("unpack + merge_runs")
+        else:                                            # (2) hash-range exchange, exact runs (first step of a read set: fixes `cap`)
             split = ops.partition(h, W)
             self._lap("partition")
             send = self._c((split[1:] - split[:-1]).contiguous())
             mat = torch.empty(W * W, dtype=torch.int64, device=send.device)
             dist.all_gather_into_tensor(mat, send)       # world x world send-count matrix: the one size exchange
             mat = mat.view(W, W).cpu()                   # the one host read of the exchange
+            self.cap = max(64, 1 << int(self.pad_slack * max(int(mat.max()), 1)).bit_length())   # the same on every rank (same matrix)
             in_splits, out_splits = mat[me].tolist(), mat[:, me].tolist()
             self._lap("all_gather counts + host read")
             payload = self._c(torch.stack([h, c.to(torch.int64)], dim=1).contiguous())     # [n, 2]: one collective for both columns
@@ -207,8 +257,10 @@ class ShardedSketch:
             self._lap("unpack + merge_runs")
         # (3) per-range distinct counts | multiplicity histogram | dictionary ids, one fused all-reduce
         M = dict_t.numel()
-        tail = torch.zeros(W + HIST_BINS + M, dtype=torch.int64, device=self.device)
+        tail = torch.zeros(W + HIST_BINS + M + 1, dtype=torch.int64, device=self.device)   # (last word: overflow flag of the fixed-size exchange)
         tail[me] = rh.numel()
+        if overflow is not None:
+            tail[-1] = overflow
         ops.histogram(rc, tail[W: W + HIST_BINS])
         lo, hi, owner_t = self._dictionary_ranges(dict_t)  # only the dictionary hashes inside this rank's range can be in rh
         ops.rank_dictionary(dict_t[lo:hi], rh, tail[W + HIST_BINS + lo: W + HIST_BINS + hi])
@@ -220,18 +272,24 @@ class ShardedSketch:
             work.wait()
             counts = self._back(counts_c)
             self._lap("fused all_reduce + wait")
-        rank1 = tail[W + HIST_BINS:]
+        rank1 = tail[W + HIST_BINS: W + HIST_BINS + M]
         if multi:
             sizes = tail[:W]
-            base = torch.cumsum(sizes, 0) - sizes        # exclusive scan: first global id of every range
+            base = torch.cumsum(sizes, 0) - sizes        # exclusive scan: first global id of every range -- consumed on the device
             ids = torch.where(rank1 > 0, rank1 - 1 + base[owner_t], torch.full_like(rank1, -1))
-            sizes_h = sizes.cpu().tolist()
-        else:                                            # one range: its size is known here, ids are the local ranks
-            ids = rank1 - 1
-            sizes_h = [int(rh.numel())]
-        self._lap("ids + host read")
-        return Score(counts=counts, ids=ids, n_distinct=int(sum(sizes_h)), hist=tail[W: W + HIST_BINS], range_hash=rh, range_count=rc,
-                     range_base=int(sum(sizes_h[:me])), range_sizes=sizes_h)
+            self._lap("ids")
+            return Score(counts, ids, tail[W: W + HIST_BINS], rh, rc, me, sizes_t=sizes, overflow_t=tail[-1])
+        self._lap("ids")                                 # one range: its size is known here, ids are the local ranks
+        return Score(counts, rank1 - 1, tail[W: W + HIST_BINS], rh, rc, me, sizes=[int(rh.numel())])
+
+    def validated(self, sc, bases_t, off_t, dict_t, k, w):
+        """the one host check of a fixed-size step, OUTSIDE the step: if some rank had more pairs for an owner than `cap` carries (the
+        read set changed under a calibrated instance), every rank sees the flag (it travelled in the fused all-reduce), drops `cap`
+        and scores again with exact runs, which also re-calibrates"""
+        if not sc.exchange_overflow:
+            return sc
+        self.cap = None
+        return self.score(bases_t, off_t, dict_t, k, w)
 
     def gather_spectrum(self, sc):
         """the whole global spectrum on every rank (sorted distinct hashes, #reads): ranges concatenated in rank order.

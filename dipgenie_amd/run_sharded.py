@@ -130,6 +130,36 @@ def run_rank(a, ops=None, lib_path=None, device=None):
     lib = RunLib(lib_path or RUN_LIB)
     H = lib.open(gfa_file=a.gfa, reads_file=a.reads, out_file=a.out, threads=a.threads, ploidy=2, R=a.R, k=a.k, w=a.w,
                  threshold=a.T, device=dev_ordinal, quiet=1)
+    err = None
+    summary = None
+    try:
+        summary = _run_rank_body(a, ops, lib, H, dev, world, rank, gloo, coll, t_start)
+    except BaseException as e:                                          # noqa: BLE001 - reported to the peers below, then re-raised
+        err = e
+    finally:
+        # The peers of a failed rank must not sit in a barrier until the backend's time-out (minutes for RCCL, 30 for gloo): every rank
+        # contributes an ok flag.  This covers the common case -- rank 0 fails in its solve while the others are already waiting here;
+        # a rank that fails INSIDE the exchange phase leaves through its launcher, which ends the group.
+        all_ok = err is None
+        if dist.is_initialized() and not isinstance(err, KeyboardInterrupt):
+            try:
+                flag = torch.tensor([1 if err is None else 0], dtype=torch.int32, device="cpu" if gloo else dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_ok = bool(int(flag.item()))
+            except Exception:                                           # noqa: BLE001 - the group is already broken
+                all_ok = False
+        lib.lib.dgr_close(H)
+    if err is not None:
+        raise err
+    if not all_ok:
+        raise RuntimeError(f"rank {rank}: another rank of the sharded run failed")
+    return summary
+
+
+def _run_rank_body(a, ops, lib, H, dev, world, rank, gloo, coll, t_start):
+    import torch
+    import torch.distributed as dist
+    from . import dist_sketch as ds
     laps = {"open_gfa": time.perf_counter() - t_start}
     t0 = time.perf_counter()
     # ---- haplotype side, sharded over the ranks (h mod world); lists exchanged as one int64 blob per rank ----
@@ -177,7 +207,7 @@ def run_rank(a, ops=None, lib_path=None, device=None):
     laps["load_reads"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     sk = ds.ShardedSketch(ops, dev, force_exchange=bool(a.force_collectives))
-    sc = sk.score(bases_t, off_t, dict_t, a.k, a.w)
+    sc = sk.validated(sk.score(bases_t, off_t, dict_t, a.k, a.w), bases_t, off_t, dict_t, a.k, a.w)
     gh, gc = sk.gather_spectrum(sc)
     if hasattr(torch, "cuda") and str(dev) != "cpu":
         torch.cuda.synchronize()
@@ -212,9 +242,6 @@ def run_rank(a, ops=None, lib_path=None, device=None):
                 json.dump(summary, f)
         if not a.quiet:
             print(json.dumps(summary), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-    lib.lib.dgr_close(H)
     return summary
 
 
@@ -242,8 +269,10 @@ def main(argv=None):
     in_group = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not in_group and a.gpus > 1:
         # launcher: one process per GPU, started before anything here touches a GPU (children, not exec)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(_find_free_port()), "-m", "dipgenie_amd.run_sharded"] + (argv if argv is not None else sys.argv[1:])
+        # (--standalone: the launcher's own rendezvous picks and holds its port; a pre-probed free port could be taken by another job
+        # between the probe and the bind)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "-m", "dipgenie_amd.run_sharded"] + (argv if argv is not None else sys.argv[1:])
         return subprocess.call(cmd)
     import torch.distributed as dist
     if in_group or a.force_collectives:

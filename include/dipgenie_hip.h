@@ -178,7 +178,8 @@ int dg_sketch_count_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int64_t n
                                    const uint64_t *hash_dev, const int32_t *count_dev, int64_t n,
                                    int32_t *counts_dev);
 /* merge several sorted (hash,count) runs stored back to back (device) into one sorted distinct
- * list with summed counts (device, capacity cap). Synchronises. */
+ * list with summed counts (device, capacity cap). Synchronises.  Entries (0xFFFFFFFFFFFFFFFF, 0) are the padding of
+ * a fixed-size exchange: a last entry with that hash and summed count 0 is dropped (a real hash has count >= 1). */
 int dg_sketch_merge_runs_dev(dg_ctx *, const uint64_t *hash_dev, const int32_t *count_dev, int64_t n_total,
                              uint64_t *out_hash_dev, int32_t *out_count_dev, int64_t cap, int64_t *n_out);
 

@@ -51,7 +51,10 @@ class CpuOps:
         if hh.size == 0:
             return h[:0], c[:0]
         uh, idx = np.unique(hh, return_index=True)
-        return torch.from_numpy(uh.view(np.int64).copy()), torch.from_numpy(np.add.reduceat(cc, idx).astype(np.int32))
+        uc = np.add.reduceat(cc, idx).astype(np.int32)
+        if uh[-1] == np.uint64(0xFFFFFFFFFFFFFFFF) and uc[-1] == 0:           # padding of the fixed-size exchange (as dg_sketch_merge_runs_dev)
+            uh, uc = uh[:-1], uc[:-1]
+        return torch.from_numpy(uh.view(np.int64).copy()), torch.from_numpy(uc.copy())
 
     def rank_dictionary(self, dict_t, h, rank1):
         d, hh, out = self._u(dict_t), self._u(h), rank1.numpy()
@@ -119,6 +122,21 @@ def _worker(rank, world, port, reads, dict_hashes, k, w, q):
             "range": np.array_equal(rh, want_h[sc.range_base: sc.range_base + rh.size]) and sum(sc.range_sizes) == want_h.size
                      and bool(np.all(ds.hash_owner(sc.range_hash, world).numpy() == rank)),
         }
+        # second step of the same instance: the fixed-size exchange (cap fixed by the first step; no size exchange, no host read) --
+        # every output identical; then a cap that is too small on purpose: the overflow flag reaches every rank, validated() repeats
+        # the step with exact runs and re-calibrates
+        assert sk.cap is not None and sk.cap >= 64
+        sc2 = sk.score(bases_t, off_t, dict_t, k, w)
+
+        def same(a, b):
+            return (torch.equal(a.counts, b.counts) and torch.equal(a.ids, b.ids) and torch.equal(a.hist, b.hist) and torch.equal(a.range_hash, b.range_hash)
+                    and torch.equal(a.range_count, b.range_count) and a.range_sizes == b.range_sizes and a.range_base == b.range_base)
+        ok["fixed_size_step"] = same(sc, sc2) and not sc2.exchange_overflow and sk.validated(sc2, bases_t, off_t, dict_t, k, w) is sc2
+        sk.cap = 4
+        sc3 = sk.score(bases_t, off_t, dict_t, k, w)
+        ok["overflow_seen_by_every_rank"] = sc3.exchange_overflow
+        sc4 = sk.validated(sc3, bases_t, off_t, dict_t, k, w)
+        ok["overflow_repaired"] = same(sc, sc4) and sk.cap >= 64
         q.put((rank, ok, hi - lo, int(rh.size)))
     finally:
         dist.destroy_process_group()

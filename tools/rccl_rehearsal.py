@@ -48,7 +48,8 @@ for _ in range(N_PASS):
     plain = ShardedSketch(ops, device).score(b4, o4, dict_t, K, W)
 torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"RCCL world-1 rehearsal OK: {o4.numel() - 1} reads, {out.n_distinct} distinct hashes; collective path {1e3 * (t1 - t0) / N_PASS:.2f} ms per pass, "
-      f"collective-free {1e3 * (t2 - t1) / N_PASS:.2f} ms (the difference is the fixed cost of 4 collectives + 2 host reads per pass)")
+      f"collective-free {1e3 * (t2 - t1) / N_PASS:.2f} ms (the difference is the fixed cost of 3 collectives per pass: hit-vector all-reduce, fixed-size all-to-all of [world, 1 + cap, 2] blocks (cap = {forced.cap}), fused all-reduce; "
+      f"no size exchange and no host read in dist_sketch.py after the calibrating first pass; overflow flag {out.exchange_overflow})")
 forced.laps = {}
 for _ in range(5):
     forced.score(b4, o4, dict_t, K, W)
