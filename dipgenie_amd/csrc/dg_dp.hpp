@@ -116,6 +116,8 @@ struct DpState {
     DpState(const DpState &) = delete;
     DpState &operator=(const DpState &) = delete;
     int32_t nV = 0, L = 0, R = 0, RP = 0, cap = 0;
+    int32_t rp_active = 0;                              // planes [0, rp_active) are swept by the fast kernels (= RP except while a segment is re-swept below its path's plane)
+    int64_t plane_limit = 1;                            // plane_limit: beyond HBM, re-sweep every segment only up to the plane its path leaves it on (0: all planes)
     bool loaded = false;
     // ---- options (dg_dp_set_option) ----
     int64_t want_digest = 0;                            // digest: accumulate per-level digests (values + back-pointers)
@@ -159,7 +161,7 @@ struct DpState {
     std::vector<int> seg_begin;
     std::vector<int64_t> ckpt_off;                     // element offset of checkpoint s (state of level seg_begin[s]-1)
     bool graph_failed = false;                          // capture or instantiation failed once: plain launches from then on
-    typedef std::tuple<int, int, const void *, int> GraphKey;     // (first level, end level, biased lattice pointer, look-ahead launches left to the prefetcher)
+    typedef std::tuple<int, int, const void *, int> GraphKey;     // (first level, end level, biased lattice pointer, look-ahead launches left to the prefetcher | planes swept << 1)
     std::map<GraphKey, hipGraphExec_t> graphs;                    // -> replayable batch
     std::map<GraphKey, std::vector<int64_t>> graph_hist;          // -> its launches by kernel variant (launch_hist)
     bool all_fast = false;

@@ -147,7 +147,7 @@ struct Run {
         const int64_t gb = S.graph_batch >= 0 ? S.graph_batch : 1000;
         // what issue_levels bakes into a captured batch besides the levels: whether the periodic look-ahead launches are left to the
         // prefetcher's far blocks -- part of the cache key (a second DP state on the device switches the prefetcher off)
-        const int pf_key = (S.pf_active && S.pf_far > 0) ? 1 : 0;
+        const int pf_key = ((S.pf_active && S.pf_far > 0) ? 1 : 0) | (S.rp_active << 1);
         for (int l0 = lb; l0 < le;) {
             const bool use_graph = gb > 0 && n_win() == 1 && S.sync_every == 0 && !S.graph_failed;
             const int l1 = use_graph ? (int)std::min<int64_t>((int64_t)l0 + gb, le) : le;
@@ -265,6 +265,8 @@ struct Run {
         } else {
             // pass 1: values only, keeping the state in front of every segment
             const int64_t dig = S.want_digest;
+            int64_t planes_swept = 0;
+            S.rp_active = S.RP;
             for (int sg = 0; sg < n_seg; ++sg) {
                 if (sg > 0)
                     DG_HIP(hipMemcpyAsync(S.d_ckpt.as<int32_t>() + S.ckpt_off[sg], state_ptr(S.seg_begin[sg] - 1),
@@ -274,6 +276,11 @@ struct Run {
             DG_HIP(hipEventRecord(S.ev[2], s));                 // (the re-sweeps below are booked under traceback_ms)
             // pass 2: last segment first -- restore its input state, re-sweep its chunks with back-pointers, walk them
             S.want_digest = 0;                                  // digests were accumulated in pass 1
+            // Along a path the recombination count only grows, and a cell of plane r gathers from planes r, r - 1, r - 2 of the level
+            // before: once the walk has left segment sg on plane r*, the cells it can meet in the segments before lie on planes
+            // <= r*, and those depend on planes <= r* only.  Every earlier segment is therefore re-swept up to the plane its
+            // successor's walk ended on (one 16-byte read per segment) -- the path uses its recombinations along the whole panel, so
+            // about half of the second pass goes away.  (The finish kernel re-scores the walked path against the DP value as ever.)
             for (int sg = n_seg - 1; sg >= 0; --sg) {
                 const int lb = S.seg_begin[sg];
                 if (sg > 0)
@@ -281,9 +288,18 @@ struct Run {
                 else
                     sweep_init_state(S, s);
                 const int c0 = sg * S.seg_chunks, c1 = std::min(n_chunks_all, c0 + S.seg_chunks);
-                if (int rc = sweep_and_walk(c0, c1, sg == n_seg - 1, false)) { S.want_digest = dig; return rc; }
+                if (int rc = sweep_and_walk(c0, c1, sg == n_seg - 1, false)) { S.want_digest = dig; S.rp_active = S.RP; return rc; }
+                if (S.plane_limit && sg > 0) {
+                    ChainState cs{0, 0, S.RP - 1, 0};
+                    if (hipMemcpyAsync(&cs, S.d_chain.p, sizeof cs, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { S.want_digest = dig; S.rp_active = S.RP; DG_HIP(hipGetLastError()); return DG_ERR_HIP; }
+                    S.rp_active = (cs.value != CHAIN_CORRUPT && cs.r >= 0 && cs.r < S.RP) ? cs.r + 1 : S.RP;
+                    planes_swept += (int64_t)S.rp_active * (S.seg_begin[sg] - S.seg_begin[sg - 1]);
+                }
             }
+            S.rp_active = S.RP;
             S.want_digest = dig;
+            if (getenv("DG_DEBUG") && S.plane_limit) fprintf(stderr, "[dipgenie_hip] run: second pass swept %.1f %% of the (level, plane) pairs before the last segment\n",
+                                                              100.0 * (double)planes_swept / std::max(1.0, (double)S.RP * (S.seg_begin[n_seg - 1] - 1)));
         }
         trace_launch_finish(S, s);
         DG_HIP(hipEventRecord(S.ev[3], s));
@@ -431,7 +447,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rowx", &S.use_rowx, 0}, {"lean_chain", &S.use_lean_chain, 0},   // take effect at the next load
         {"segment_cells", &S.segment_cells, 0}, {"sync_every", &S.sync_every, 0}, {"rc_t0_ns", &S.rc_t0_ns, 0}, {"rc_tg_ps", &S.rc_tg_ps, 0},
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
-        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1},
+        {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1}, {"plane_limit", &S.plane_limit, 0},
 #ifdef DG_SYM
         {"sym", &S.use_sym, 0}, {"sym_min_k2", &S.sym_min_k2, 1}, {"sym_rc", &S.sym_rc, 1}, {"sym_dbg", &S.sym_dbg, 0},
 #endif

@@ -595,7 +595,7 @@ static void choose_rc(const DpState &S, const LevelDesc &d, int l, int rc_sel, i
             if (pass == 1 && cand[q] > 4) continue;
             const double rows = pass ? (double)d.k2 + 4.0 * d.n_heavy : (double)d.k2;
             const double chain = pass ? std::max((double)COOP_MIN, std::ceil(dmax / 4.0)) + 1.0 : dmax;
-            const double W = rows * d.nblocks * ((S.RP + cand[q] - 1) / cand[q]);
+            const double W = rows * d.nblocks * ((S.rp_active + cand[q] - 1) / cand[q]);
             const double T = std::max(1.0, W / (double)S.rc_cap) * ((double)S.rc_t0_ns + chain * cand[q] * (double)S.rc_tg_ps * 1e-3) + W * (double)S.rc_tw_ps * 1e-3;
             if (T <= best) { best = T; rc = cand[q]; coop = pass == 1; }   // ties: the larger RC (fewer waves)
         }
@@ -616,7 +616,7 @@ void sweep_launch_level(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         bool coop;
         choose_rc(S, d, l, X.rc_sel, rc, coop);
         S.launch_hist[(rc & 63) * 4 + (d.fast_ok == 2 ? 2 : 0) + (coop ? 1 : 0)]++;
-        const int nch = (S.RP + rc - 1) / rc;
+        const int nch = (S.rp_active + rc - 1) / rc;              // (rp_active < RP: re-sweep of a segment whose path stays below that plane, dg_dp_run.hip)
         const dim3 grid((unsigned)((d.nblocks + 3) / 4), (unsigned)nch, (unsigned)(d.k2 + (coop ? 4 * d.n_heavy : 0)));
         const dim3 pgrid((unsigned)((d.nblocks + DG_PLAIN_GW - 1) / DG_PLAIN_GW), (unsigned)((nch + DG_PLAIN_CH - 1) / DG_PLAIN_CH), grid.z);
         const int32_t *hv = S.d_heavy.as<int32_t>();

@@ -519,7 +519,7 @@ int dp_load(dg_ctx *c, const dg_dp_graph *g) {
     DpState &S = *c->dp;
     graphs_clear(S);
     S.loaded = false;
-    S.nV = nV; S.L = L; S.R = R; S.RP = R + 1;
+    S.nV = nV; S.L = L; S.R = R; S.RP = R + 1; S.rp_active = S.RP;
     hipStream_t s = c->stream;
     PoolPause pause(S);                                         // the pool thread maps no chunk while this function allocates
     std::vector<int32_t> dtrans;

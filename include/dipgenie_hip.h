@@ -105,6 +105,7 @@ int dg_dp_get_level_digest(dg_ctx *, uint64_t *out, int64_t n);
  *   delta_overlap 0|1|2   score deltas beside the sweep: off / on graphs of >= 32,000 levels / whenever possible (tests)
  *   warm_ahead n          levels per Infinity-Cache look-ahead batch (0: off)
  *   segment_cells, lattice_chunk_cells, delta_cap_entries   force checkpoint + recompute / chunk size / delta windows (tests)
+ *   plane_limit 0|1       lattice beyond HBM: re-sweep every segment only up to the recombination plane its path leaves it on (default 1; 0: all planes)
  *   sync_every n          drain the stream every n level launches (rocprofv3 --pmc)
  *   side_stream -1|0|1    L2 prefetcher + score deltas beside the sweep: -1 (default) while this is the only DP state on its device, 0 never, 1 always
  *   test_poison_level l, test_poison_byte b   tests: fill level l of the back-pointer lattice with byte b between sweep and walk (dg_dp_run must answer DG_ERR_STATE)

@@ -38,8 +38,8 @@ def test_config5_panel_one_answer_in_every_execution_mode(c5_panel, gpu_ctx):
     assert g.R == 32 and g.n_levels > 200
     ref = orc.dp_solve(g, want_digest=True)
     assert ref["value"] == summ["dp_value"]
-    modes = [{}, {"segment_cells": max(1, int(ref["cells"]) // 7)}, {"graph_batch": 0}, {"lattice_chunk_cells": max(2, int(ref["cells"]) // 5)},
-             {"fast": 0}]
+    modes = [{}, {"segment_cells": max(1, int(ref["cells"]) // 7)}, {"segment_cells": max(1, int(ref["cells"]) // 23), "plane_limit": 0},
+             {"segment_cells": max(1, int(ref["cells"]) // 23), "graph_batch": 0}, {"graph_batch": 0}, {"lattice_chunk_cells": max(2, int(ref["cells"]) // 5)}, {"fast": 0}]
     try:
         gpu_ctx.dp_set_option("digest", 1)
         for m in modes:
@@ -49,9 +49,9 @@ def test_config5_panel_one_answer_in_every_execution_mode(c5_panel, gpu_ctx):
             assert (out.value, out.s_het, out.p1, out.p2) == (ref["value"], ref["s_het"], ref["p1"], ref["p2"]), m
             assert np.array_equal(gpu_ctx.dp_level_digest(g.n_levels)[1:], ref["digest"][1:]), m
             for k in m:
-                gpu_ctx.dp_set_option(k, {"segment_cells": 0, "graph_batch": -1, "lattice_chunk_cells": 1 << 32, "fast": 1}[k])
+                gpu_ctx.dp_set_option(k, {"segment_cells": 0, "graph_batch": -1, "lattice_chunk_cells": 1 << 32, "fast": 1, "plane_limit": 1}[k])
     finally:
-        for k, v in {"digest": 0, "segment_cells": 0, "graph_batch": -1, "lattice_chunk_cells": 1 << 32, "fast": 1}.items():
+        for k, v in {"digest": 0, "segment_cells": 0, "graph_batch": -1, "lattice_chunk_cells": 1 << 32, "fast": 1, "plane_limit": 1}.items():
             gpu_ctx.dp_set_option(k, v)
 
 
@@ -80,8 +80,9 @@ def test_config5_5mbp_tier_naturally_segmented(built_hip, tmp_path_factory):
     assert s32["dp_segments"] > 1 and s32["dp_chunks"] > s32["dp_segments"], s32          # beyond HBM: checkpoint + recompute
     assert s32["cells"] > 5e11 and s32["n_levels"] > 2e5 and s32["dp_value"] > 0 and s32["r1"] <= 32 and s32["r2"] <= 32
     assert s32["len1"] > 4_500_000 and s32["len2"] > 4_500_000
-    fb, s32b = run("r32b", 32, "lattice_chunk_cells=%d" % (3 << 30))                       # 6 GB chunks: other chunk and segment boundaries
+    fb, s32b = run("r32b", 32, "lattice_chunk_cells=%d,plane_limit=0" % (3 << 30))         # 6 GB chunks: other chunk and segment boundaries; every plane re-swept
     assert fb == fa and s32b["dp_value"] == s32["dp_value"] and (s32b["dp_chunks"], s32b["dp_segments"]) != (s32["dp_chunks"], s32["dp_segments"])
+    assert s32["dp_traceback_ms"] < 0.85 * s32b["dp_traceback_ms"], (s32["dp_traceback_ms"], s32b["dp_traceback_ms"])   # the plane-limited second pass is the shorter one
     _, s28 = run("r28", 28)
     _, s36 = run("r36", 36)
     assert s28["dp_value"] <= s32["dp_value"] <= s36["dp_value"], (s28["dp_value"], s32["dp_value"], s36["dp_value"])
