@@ -240,9 +240,19 @@ def config4_one_run_block(cache, gfa, device, cores):
     out["run_sharded_wall_s"] = time.time() - t0
     if p.returncode != 0:
         return {"error": "run_sharded: " + p.stderr.decode()[-300:]}
+    time.sleep(5.0)
+    t0 = time.time()                                                     # the same job as ONE C++ process: bin/DipGenie --gpus 1 (RCCL through librccl, one rank)
+    p2 = subprocess.run([os.path.join(ROOT, "bin", "DipGenie"), "-t", str(cores), "-p2", "-R18", "--gpus", "1", "--shard-transport", "rccl", "--shard-devices", str(device),
+                         "-g", gfa, "-r", reads30, "-o", os.path.join(d, "cli_sharded.fa"), "-J", os.path.join(d, "cli_sharded.json")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    out["cli_gpus1_rccl_wall_s"] = time.time() - t0
+    if p2.returncode != 0:
+        return {"error": "DipGenie --gpus 1: " + p2.stderr.decode()[-300:]}
+    cs = json.load(open(os.path.join(d, "cli_sharded.json")))
+    out["cli_gpus1_rccl"] = {k: cs[k] for k in ("dictionary", "dictionary_hits", "shard_sketch_ms", "shard_exchange_ms", "spectrum")}
+    out["cli_gpus1_rccl"]["stages_s"] = {k: v for k, v in cs["stages"].items() if k.startswith("sharded")}
     sm = json.load(open(os.path.join(d, "sharded.json")))
     md5 = lambda f: hashlib.md5(open(f, "rb").read()).hexdigest()
-    out.update(run_sharded_inside_s=sm["wall_s"], run_sharded_stages_s=sm["stages_s"], fasta_identical=md5(os.path.join(d, "cli.fa")) == md5(os.path.join(d, "sharded.fa")),
+    out.update(run_sharded_inside_s=sm["wall_s"], run_sharded_stages_s=sm["stages_s"], fasta_identical=md5(os.path.join(d, "cli.fa")) == md5(os.path.join(d, "sharded.fa")) == md5(os.path.join(d, "cli_sharded.fa")),
                note="run_sharded_wall_s - run_sharded_inside_s = interpreter + torch import + process-group start-up of the launcher; one rank, RCCL, collective path forced "
                     "(N > 1 under RCCL has never run: one GPU per lease)")
     return out

@@ -61,6 +61,7 @@ SYMBOLS = [
     "dg_sketch_partition_dev", "dg_sketch_rank_dictionary_dev", "dg_sketch_histogram_dev",
     "dg_anchor_begin", "dg_anchor_add_haplotype", "dg_anchor_finish", "dg_dp_solve_haploid", "dg_dp_get_table_digest", "dg_hip_versions", "dg_anchor_add_haplotype_sketched",
     "dg_sketch_set_option", "dg_sketch_get_stat", "dg_sketch_count_rank_dictionary_dev",
+    "dg_shard_create", "dg_shard_destroy", "dg_shard_n_ranks", "dg_shard_ctx", "dg_shard_score_reads",
 ]
 
 lib.dg_create.restype = C.c_void_p

@@ -14,6 +14,7 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "pipeline.hpp"
 
@@ -120,6 +121,65 @@ static void b_hint(void *c, int64_t est_cells) {   // overlap the lattice reserv
     if (x && bytes >= 4e9) dg_dp_prealloc(x, bytes > 8e18 ? 0 : (int64_t)bytes);   // small lattices allocate instantly anyway
 }
 
+// ---- --gpus N: minimizer scoring sharded over N devices inside this one process (BASELINE configs[3]) ----
+// One host thread per device.  Haplotype h is sketched on device h mod N (index_kmers is independent per haplotype, solver.cpp:470-473);
+// the reads are scored by dg_shard_score_reads (contiguous blocks, RCCL all-reduce of the dictionary hit vector, hash-range exchange,
+// per-owner merge: dipgenie_amd/csrc/dg_shard.hip); spectrum and sketches are handed to the host pipeline exactly as the Python
+// driver hands them in (Pipeline::inj_*), and everything from the anchor join on -- fit, graph, DP, FASTA -- runs on the first device.
+struct ShardInfo { int gpus = 0, transport = 0; int64_t n_dict = 0, dict_hits = 0; double ms_sketch = 0, ms_exchange = 0, wall_s = 0; };
+static int run_sharded(dg::Pipeline &p, int n_gpus, int transport, const std::vector<int> &devices, ShardInfo &info, std::string &err) {
+    const double t0 = dg::now_s();
+    p.sum = dg::Summary();
+    if (p.load_graph(err)) return -1;
+    if (p.load_reads(err)) return -1;
+    dg_shard *sh = dg_shard_create(n_gpus, devices.empty() ? nullptr : devices.data(), transport);
+    if (!sh) { err = dg_last_error(); return -2; }                       // no gfx950 device / no librccl: no fallback
+    const double t1 = dg::now_s();
+    p.inj_hap.assign(p.num_walks, {});
+    std::vector<std::string> terr((size_t)n_gpus);
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_gpus; ++r)
+        th.emplace_back([&, r] {
+            dg_ctx *c = dg_shard_ctx(sh, r);
+            for (uint32_t h = (uint32_t)r; h < p.num_walks; h += (uint32_t)n_gpus) {
+                const std::string seq = p.haplotype_sequence(h);
+                uint64_t *hh = nullptr; int64_t *pp = nullptr; int64_t n = 0;
+                if (dg_sketch_haplotype(c, seq.data(), (int64_t)seq.size(), p.opt.k, p.opt.w, &hh, &pp, &n) != DG_OK) { terr[r] = dg_last_error(); return; }
+                p.inj_hap[h].hash.assign(hh, hh + n); p.inj_hap[h].pos.assign(pp, pp + n); p.inj_hap[h].set = true;
+                dg_free(hh); dg_free(pp);
+            }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : terr) if (!e.empty()) { err = "haplotype sketch: " + e; dg_shard_destroy(sh); return -1; }
+    std::vector<uint64_t> hap_hash;
+    for (auto &hs : p.inj_hap) hap_hash.insert(hap_hash.end(), hs.hash.begin(), hs.hash.end());
+    std::vector<int64_t> off(p.reads.size() + 1, 0);
+    for (size_t r = 0; r < p.reads.size(); ++r) off[r + 1] = off[r] + (int64_t)p.reads[r].second.size();
+    std::string bases;
+    bases.reserve((size_t)off.back());
+    for (auto &rd : p.reads) bases += rd.second;
+    const int64_t n_reads = (int64_t)p.reads.size();
+    p.reads.clear(); p.reads.shrink_to_fit();
+    const double t2 = dg::now_s();
+    uint64_t *sph = nullptr; int32_t *spc = nullptr; int64_t nsp = 0;
+    std::vector<int64_t> hist(4096, 0);
+    if (dg_shard_score_reads(sh, bases.data(), off.data(), n_reads, p.opt.k, p.opt.w, hap_hash.data(), (int64_t)hap_hash.size(), &sph, &spc, &nsp, hist.data(), (int)hist.size(),
+                             &info.n_dict, &info.dict_hits, &info.ms_sketch, &info.ms_exchange) != DG_OK) { err = dg_last_error(); dg_shard_destroy(sh); return -1; }
+    p.inj_sp_hash.assign(sph, sph + nsp); p.inj_sp_count.assign(spc, spc + nsp); p.inj_hist = hist; p.spectrum_injected = true;
+    dg_free(sph); dg_free(spc);
+    const double t3 = dg::now_s();
+    if (!p.opt.quiet) fprintf(stderr, "[dg::shard] %d ranks (%s): haplotype sketches %.3f s, read scoring %.3f s (slowest rank: sketch %.2f ms, exchange + merge %.2f ms); dictionary %lld, hit by reads %lld\n",
+                              n_gpus, transport == 0 ? "RCCL" : "host-staged", t2 - t1, t3 - t2, info.ms_sketch, info.ms_exchange, (long long)info.n_dict, (long long)info.dict_hits);
+    p.sum.stage_s.emplace_back("sharded: contexts + communicator", t1 - t0 > 0 ? t1 - t0 : 0);
+    p.sum.stage_s.emplace_back("sharded: haplotype sketches", t2 - t1);
+    p.sum.stage_s.emplace_back("sharded: read scoring", t3 - t2);
+    g_lazy.ctx = dg_shard_ctx(sh, 0); g_lazy.joined = true;              // the rest of the pipeline: the first device's context
+    info.gpus = n_gpus; info.transport = transport;
+    const int rc = p.run_loaded(err);
+    info.wall_s = dg::now_s() - t0;
+    return rc;                                                           // (the shard object lives until the process exits: its first context is in use)
+}
+
 static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
     fprintf(fp, "Usage: PHI -g <target.gfa> -r <reads.fa> -o <haplotype.fasta> \n");
     fprintf(fp, "Options:\n");
@@ -135,6 +195,7 @@ static void usage(FILE *fp, const dg::Options &o) {   // main.cpp:90-110
     fprintf(fp, "    -o INT       Output haplotype [%s]\n", o.hap_file.c_str());
     fprintf(fp, "    -d bool      Debug mode [%d]\n", (int)o.debug);
     fprintf(fp, "    -G INT       (MI355X build) HIP device ordinal [0]\n");
+    fprintf(fp, "    --gpus INT   (MI355X build) shard the minimizer scoring over INT devices (RCCL); the DP runs on the first [1]\n");
 }
 
 int main(int argc, char **argv) {
@@ -148,6 +209,26 @@ int main(int argc, char **argv) {
     std::string json;
     for (int i = 1; i < argc; ++i)
         if (!strcmp(argv[i], "--version")) { fprintf(stderr, "PHI version: 1.0 (dipgenie-mi355x)\n"); return 0; }
+    // long options of this build, taken out of argv before the reference's getopt string sees it:
+    //   --gpus N, --shard-transport rccl|host (host: tests on a one-GPU box), --shard-devices a,b,c (default 0 .. N-1; host transport: -G for every rank)
+    int n_gpus = 1, shard_transport = -1;
+    std::vector<int> shard_devices;
+    {
+        int w = 1;
+        for (int i = 1; i < argc; ++i) {
+            auto val = [&](const char *name) -> const char * {
+                const size_t n = strlen(name);
+                if (!strncmp(argv[i], name, n) && argv[i][n] == '=') return argv[i] + n + 1;
+                if (!strcmp(argv[i], name) && i + 1 < argc) return argv[++i];
+                return nullptr;
+            };
+            if (!strncmp(argv[i], "--gpus", 6)) { const char *v = val("--gpus"); if (v) { n_gpus = atoi(v); continue; } }
+            if (!strncmp(argv[i], "--shard-transport", 17)) { const char *v = val("--shard-transport"); if (v) { shard_transport = !strcmp(v, "host") ? 1 : 0; continue; } }
+            if (!strncmp(argv[i], "--shard-devices", 15)) { const char *v = val("--shard-devices"); if (v) { for (const char *q = v; *q;) { shard_devices.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; ++q; } continue; } }
+            argv[w++] = argv[i];
+        }
+        argc = w;
+    }
     int c;
     // reference option string: "x:p:d:c:l:s:m:R:P:a:q:T:H:N:m:h:k:w:t:g:r:o:DSc" (main.cpp:39); -G -J -D -A -X are ours
     while ((c = getopt(argc, argv, "x:p:d:c:l:s:m:R:P:a:q:T:H:N:h:k:w:t:g:r:o:G:J:D:A:X")) >= 0) {
@@ -176,7 +257,10 @@ int main(int argc, char **argv) {
         return 1;
     }
     const double t0 = dg::now_s();
-    g_lazy.start(device, p.opt.k, p.opt.w);
+    const bool sharded = n_gpus > 1 || shard_transport >= 0;
+    if (n_gpus < 1 || n_gpus > 64) { fprintf(stderr, "[E::main] --gpus must be 1 .. 64\n"); return 1; }
+    if (sharded && p.opt.ploidy != 2) { fprintf(stderr, "[E::main] --gpus shards the diploid path (-p2)\n"); return 1; }
+    if (!sharded) g_lazy.start(device, p.opt.k, p.opt.w);
     p.be.ctx = &g_lazy;
     p.be.sketch_reads = b_sketch_reads;
     p.be.sketch_haplotype = b_sketch_hap;
@@ -193,7 +277,15 @@ int main(int argc, char **argv) {
     p.be.last_error = b_last_error;
     std::string err;
     if (dbg_tl) fprintf(stderr, "[dg::main] run() starts %.3f s after main\n", dg::now_s() - t0);
-    int rc = p.run(err);
+    ShardInfo shard;
+    int rc;
+    if (sharded) {
+        if (shard_transport < 0) shard_transport = 0;
+        if (shard_devices.empty() && shard_transport == 1) shard_devices.assign((size_t)n_gpus, device);   // host-staged: every rank on -G
+        if (!shard_devices.empty() && (int)shard_devices.size() != n_gpus) { fprintf(stderr, "[E::main] --shard-devices needs %d entries\n", n_gpus); return 1; }
+        rc = run_sharded(p, n_gpus, shard_transport, shard_devices, shard, err);
+        if (rc == -2) { fprintf(stderr, "[E::main] %s\n", err.c_str()); return 2; }
+    } else rc = p.run(err);
     if (dbg_tl) {
         fprintf(stderr, "[dg::main] run() returned %.3f s after main", dg::now_s() - t0);
         for (auto &st : p.sum.stage_s) if (st.first == "total") fprintf(stderr, " (its own total: %.3f s)", st.second);
@@ -213,10 +305,12 @@ int main(int argc, char **argv) {
         if (f) {
             fprintf(f, "{\"dp_value\": %d, \"s_het\": %d, \"r1\": %d, \"r2\": %d, \"obj\": %d, \"len1\": %lld, \"len2\": %lld, "
                        "\"spectrum\": %lld, \"n_levels\": %lld, \"n_vertices\": %lld, \"cells\": %llu, \"relaxations\": %llu, "
+                       "\"gpus\": %d, \"shard_transport\": \"%s\", \"dictionary\": %lld, \"dictionary_hits\": %lld, \"shard_sketch_ms\": %.3f, \"shard_exchange_ms\": %.3f, "
                        "\"best_r_haploid\": %d, \"fit_nll\": %.17g, \"dp_segments\": %d, \"dp_chunks\": %d, \"dp_forward_ms\": %.3f, \"dp_traceback_ms\": %.3f, \"dp_forward_launches\": %lld, \"dp_edge_pairs\": %llu, \"dp_colour_entries\": %llu, \"stages\": {",
                     p.sum.dp_value, p.sum.s_het, p.sum.r1, p.sum.r2, p.sum.obj, (long long)p.sum.len1, (long long)p.sum.len2,
                     (long long)p.sum.spectrum, (long long)p.sum.n_levels, (long long)p.sum.n_vertices,
-                    (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, p.sum.best_r_haploid, p.sum.fit.nll,
+                    (unsigned long long)p.sum.cells, (unsigned long long)p.sum.relaxations, sharded ? shard.gpus : 1, !sharded ? "none" : (shard.transport ? "host" : "rccl"),
+                    (long long)shard.n_dict, (long long)shard.dict_hits, shard.ms_sketch, shard.ms_exchange, p.sum.best_r_haploid, p.sum.fit.nll,
                     have_tm ? tm.n_segments : 0, have_tm ? tm.n_chunks : 0, have_tm ? tm.forward_ms : 0.f, have_tm ? tm.traceback_ms : 0.f,
                     have_tm ? (long long)tm.n_forward_launches : 0LL, have_tm ? (unsigned long long)tm.edge_pairs : 0ULL, have_tm ? (unsigned long long)tm.colour_entries : 0ULL);
             for (size_t i = 0; i < p.sum.stage_s.size(); ++i)

@@ -201,6 +201,27 @@ int dg_sketch_count_rank_dictionary_dev(dg_ctx *, const uint64_t *dict_dev, int6
 /* hist_dev[min(count, n_bins-1)] += 1 per entry: this range's share of Hist_kmer (solver.cpp:745-755).  Asynchronous. */
 int dg_sketch_histogram_dev(dg_ctx *, const int32_t *count_dev, int64_t n, int n_bins, uint64_t *hist_dev);
 
+/* ---- read-sharded scoring inside ONE process (bin/DipGenie --gpus N; SURVEY.md s8e, BASELINE configs[3]) ----
+ * One host thread and one dg_ctx per rank; transport 0 = RCCL (librccl is dlopen-ed here, an in-process communicator over the
+ * `devices`, one device per rank), transport 1 = the same exchange staged through host memory between the rank threads (tests on a
+ * one-GPU box, where several ranks share a device).  dg_shard_ctx(s, r) is rank r's context: the caller sketches the haplotypes
+ * h = r (mod N) on it from N threads of its own (index_kmers is independent per haplotype, solver.cpp:470-473) and runs the rest of
+ * the pipeline on rank 0's.
+ * dg_shard_score_reads replaces compute_hashes over all reads + Sp_R + kmer_count + Hist_kmer (solver.cpp:526-555, 711-755):
+ * every rank sketches its contiguous block of the reads, the hit vector of the haplotype-minimizer dictionary (the sorted distinct
+ * set of hap_hash[n_hap_hash], built on every device) is all-reduced over RCCL, the (hash, #reads) runs are exchanged by hash range
+ * in one grouped send / receive and merged by their owners.  Out: sp_hash / sp_count (malloc-ed, dg_free) = Sp_R's keys in ascending
+ * order with kmer_count; hist[n_bins] (multiplicities >= n_bins - 1 share the last bin); n_dict, dict_hits = size of the dictionary and
+ * how many of its hashes some read holds; the slowest rank's sketch and exchange times (HIP events, ms).  Any of the last five may be NULL. */
+typedef struct dg_shard dg_shard;
+dg_shard *dg_shard_create(int n_ranks, const int *devices, int transport);   /* devices NULL: 0 .. n_ranks-1; NULL on error (dg_last_error) */
+void      dg_shard_destroy(dg_shard *);
+int       dg_shard_n_ranks(dg_shard *);
+dg_ctx   *dg_shard_ctx(dg_shard *, int rank);
+int       dg_shard_score_reads(dg_shard *, const char *bases, const int64_t *read_off, int64_t n_reads, int k, int w,
+                               const uint64_t *hap_hash, int64_t n_hap_hash, uint64_t **sp_hash, int32_t **sp_count, int64_t *n_sp,
+                               int64_t *hist, int n_bins, int64_t *n_dict, int64_t *dict_hits, double *ms_sketch_max, double *ms_exchange_max);
+
 /* ---- haplotype index with vertex spans + anchor join / filter / sort ----
  * Replaces, for all haplotypes at once, Solver::index_kmers including its position -> vertex-list mapping
  * (src/solver.cpp:277-363), Solver::compute_anchors and the Anchor_hits assembly (:415-446, 560-575), the shared-anchor

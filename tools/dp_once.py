@@ -13,6 +13,8 @@ if os.environ.get("DG_OPTS"):
         k_, v_ = kv.split("="); ctx.dp_set_option(k_, int(v_))
 if os.environ.get("DG_GRAPH_BATCH"): ctx.dp_set_option("graph_batch", int(os.environ["DG_GRAPH_BATCH"]))
 ctx.dp_load_graph(g)
+if os.environ.get("DG_DUMP_MAPS"):                      # tools/pmc_abort_probe.sh: the memory map every later crash address is resolved against
+    open(os.environ["DG_DUMP_MAPS"], "w").write(open("/proc/self/maps").read())
 for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     out = ctx.dp_run()
     tm = ctx.dp_timing()
