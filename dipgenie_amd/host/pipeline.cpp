@@ -32,6 +32,8 @@ double now_s() {
 
 void Pipeline::stamp(const char *name, double t0) {
     double dt = now_s() - t0;
+    static std::mutex mu;                                              // (the sharded CLI reads the GFA and the reads on two threads)
+    std::lock_guard<std::mutex> lk(mu);
     sum.stage_s.emplace_back(name, dt);
     if (!opt.quiet) fprintf(stderr, "[dg::stage] %-28s %.3f s\n", name, dt);
 }
