@@ -244,7 +244,7 @@ class ShardedSketch:
             mat = torch.empty(W * W, dtype=torch.int64, device=send.device)
             dist.all_gather_into_tensor(mat, send)       # world x world send-count matrix: the one size exchange
             mat = mat.view(W, W).cpu()                   # the one host read of the exchange
-            self.cap = max(64, 1 << int(self.pad_slack * max(int(mat.max()), 1)).bit_length())   # the same on every rank (same matrix)
+            self.cap = max(64, -(-int(self.pad_slack * max(int(mat.max()), 1)) // 4096) * 4096)   # 1.25 x the largest run, rounded up to 4,096 pairs; the same on every rank (same matrix)
             in_splits, out_splits = mat[me].tolist(), mat[:, me].tolist()
             self._lap("all_gather counts + host read")
             payload = self._c(torch.stack([h, c.to(torch.int64)], dim=1).contiguous())     # [n, 2]: one collective for both columns
