@@ -26,7 +26,12 @@ def pmc(name):
             if r["counter"] in (name, "SQ_WAVES"): n += int(r["dispatches"])
     return s, n
 wr, n_wr = pmc("WRITE_SIZE"); fe, n_fe = pmc("FETCH_SIZE"); sq, n_sq = pmc("SQ")
-visits = 2.0 * cells                                    # every level is swept twice beyond HBM (value pass + recompute pass)
+visits = 2.0 * cells                                    # nominal: every level is swept twice beyond HBM (value pass + recompute pass; the second pass is plane-limited, below)
+import os, re
+swept = None
+if os.path.exists(f"{d}/plain.err"):
+    m = re.search(r"second pass swept ([0-9.]+) % of the \(level, plane\) pairs", open(f"{d}/plain.err").read())
+    swept = float(m.group(1)) if m else None
 w_b = wr["WRITE_SIZE"] * 1024.0; f_raw = fe["FETCH_SIZE"] * 1024.0
 alg = 32.0 * cells + 16.0 * plain.get("dp_edge_pairs", plain["relaxations"] // 33) + 4.0 * plain.get("dp_colour_entries", 0)
 res = {
@@ -34,6 +39,7 @@ res = {
     "cells": cells, "n_levels": plain["n_levels"], "dp_segments": plain["dp_segments"], "dp_chunks": plain["dp_chunks"],
     "untraced_run": {"forward_ms": fwd_ms, "recompute_and_walk_ms": tb_ms, "value_pass_cells_per_s": cells / (fwd_ms / 1e3),
                      "recompute_factor": (fwd_ms + tb_ms) / fwd_ms},
+    "second_pass_planes_swept_pct_before_last_segment": swept,
     "kernel_trace": {"sweep_launches": n_calls, "total_ms": tot_ns / 1e6, "avg_launch_us_under_tracer": tot_ns / n_calls / 1e3, "per_variant": stats},
     "pmc": {"dispatches": {"WRITE_SIZE": n_wr, "FETCH_SIZE": n_fe, "SQ": n_sq},
             "WRITE_SIZE_bytes": w_b, "FETCH_SIZE_raw_bytes": f_raw, "FETCH_SIZE_calibrated_bytes": [1.5 * f_raw, 2.0 * f_raw],
