@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <thread>
 
@@ -37,7 +38,7 @@ struct Rccl {                                            // librccl entry points
     bool load(std::string &err) {
         if (lib) return true;
         for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+            if ((lib = dlopen(n, RTLD_LAZY | RTLD_LOCAL))) break;
         if (!lib) { err = std::string("librccl not found: ") + dlerror(); return false; }
 #define DG_SYM(F) do { F = (decltype(F))dlsym(lib, "nccl" #F); if (!F) { err = "librccl lacks nccl" #F; return false; } } while (0)
         DG_SYM(CommInitAll); DG_SYM(CommDestroy); DG_SYM(GetErrorString); DG_SYM(AllReduce); DG_SYM(Send); DG_SYM(Recv); DG_SYM(GroupStart); DG_SYM(GroupEnd);
@@ -86,16 +87,22 @@ extern "C" dg_shard *dg_shard_create(int n_ranks, const int *devices, int transp
         for (int r = 0; r < n_ranks; ++r)
             for (int q = 0; q < r; ++q)
                 if (S->dev[q] == S->dev[r]) { dgi::set_error("dg_shard_create: RCCL needs one device per rank (device %d given twice)", S->dev[r]); delete S; return nullptr; }
+    const bool dbg = getenv("DG_DEBUG") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    const double tc0 = now();
     for (int r = 0; r < n_ranks; ++r) {
         dg_ctx *c = dg_create(S->dev[r]);                // (no CPU fallback: fails without a gfx950 device)
         if (!c) { for (dg_ctx *q : S->ctx) dg_destroy(q); delete S; return nullptr; }
         S->ctx.push_back(c);
     }
+    const double tc_ctx = now();
     if (transport == 0) {
         std::string err;
         if (!S->rccl.load(err)) { dgi::set_error("dg_shard_create: %s", err.c_str()); for (dg_ctx *q : S->ctx) dg_destroy(q); delete S; return nullptr; }
         S->comm.assign(n_ranks, nullptr);
+        const double tc1 = now();
         const ncclResult_t e = S->rccl.CommInitAll(S->comm.data(), n_ranks, S->dev.data());
+        if (dbg) fprintf(stderr, "[dipgenie_hip] shard: %d contexts %.3f s, librccl bound %.3f s, ncclCommInitAll %.3f s\n", n_ranks, tc_ctx - tc0, tc1 - tc_ctx, now() - tc1);
         if (e != ncclSuccess) { dgi::set_error("ncclCommInitAll(%d devices): %s", n_ranks, S->rccl.GetErrorString(e)); for (dg_ctx *q : S->ctx) dg_destroy(q); delete S; return nullptr; }
     }
     return S;

@@ -43,6 +43,9 @@ struct LazyCtx {
         if (!joined) { th.join(); joined = true; }
         return ctx;
     }
+    // the reference's error exits (exit(1) in read_gfa on a reverse-strand walk step, solver.cpp:116-119) run the static destructors while
+    // the side thread may still be creating the context: a joinable std::thread there would end the process with SIGABRT instead of code 1
+    ~LazyCtx() { if (th.joinable()) th.join(); }
 };
 static LazyCtx g_lazy;
 
