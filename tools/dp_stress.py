@@ -12,9 +12,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 990000
 ctx = capi.Context(0)
 rng = np.random.default_rng(seed0)
-modes = [{}, {"graph_batch": 5}, {"graph_batch": 0}, {"warm_ahead": 0}, {"segment_cells": 3000}, {"delta_cap_entries": 500}, {"adaptive_rc": 0}, {"coop": 2}, {"rowx": 0},
+modes = [{}, {"graph_batch": 5}, {"graph_batch": 0}, {"warm_ahead": 0}, {"segment_cells": 3000}, {"segment_cells": 900, "plane_limit": 0}, {"segment_cells": 700}, {"delta_cap_entries": 500}, {"adaptive_rc": 0}, {"coop": 2}, {"rowx": 0},
          {"lean_chain": 0}, {"l2_prefetch": 0}, {"delta_overlap": 2}, {"pf_far": 0}, {"host_tables": 1}]
-defaults = {"graph_batch": -1, "warm_ahead": 128, "segment_cells": 0, "delta_cap_entries": 0, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128, "host_tables": 0}
+defaults = {"plane_limit": 1, "graph_batch": -1, "warm_ahead": 128, "segment_cells": 0, "delta_cap_entries": 0, "adaptive_rc": 1, "coop": 1, "rowx": 1, "lean_chain": 1, "l2_prefetch": 6, "delta_overlap": 1, "pf_far": 128, "host_tables": 0}
 bad = 0
 for t in range(n):
     kw = dict(n_levels=int(rng.integers(2, 120)), max_width=int(rng.choice([3, 8, 20, 45, 70])), R=int(rng.choice([0, 1, 3, 6, 18, 33])),
