@@ -130,6 +130,7 @@ struct DpState {
     int64_t test_poison_level = 0, test_poison_byte = 0xFF;   // test_poison_*: overwrite one level of the lattice between sweep and walk (tests of the corrupt-lattice path)
     // (measurement build -DDG_SYM only; the product library has neither the kernels nor the options)
     int64_t use_sym = 1;                                // sym: symmetric form of the sweep on wide levels (1: levels at least sym_min_k2 wide, 2: wherever the form exists, 0: off)
+    int64_t sym_fold = 0;                               // sym_fold: 1 = the (tile, block) pairs above the diagonal dealt to the grid without holes (lean levels; measured 2 % slower than the rectangular grid with its idle workgroups)
     int64_t sym_dbg = 0;                                // (experiments: 1 no fan-in workgroups, 4 no mirror stores, 8 no gathers, 16 empty kernel, 32 first load round only -- results void)
     int64_t sym_min_k2 = 160, sym_rc = 4;               // sym_min_k2, sym_rc: width from which a level takes the symmetric form; recombination counts per task there (1-4, 6, 8)
     int64_t host_tables = 0;                            // host_tables: 1 = build the tables on the host and upload them (dg_dp_tables.hip; parity twin of dg_dp_build.hip)

@@ -449,7 +449,7 @@ extern "C" int dg_dp_set_option(dg_ctx *c, const char *key, int64_t v) {
         {"rc_tw_ps", &S.rc_tw_ps, 0}, {"bp_nt_min_cells", &S.bp_nt_min_cells, 0}, {"warm_ahead", &S.warm_ahead, 0}, {"graph_batch", &S.graph_batch, -1}, {"l2_prefetch", &S.l2_prefetch, 0}, {"delta_overlap", &S.delta_overlap, 0}, {"pf_far", &S.pf_far, 0},
         {"host_threads", &S.host_threads, 1}, {"host_tables", &S.host_tables, 0}, {"side_stream", &S.side_stream, -1}, {"plane_limit", &S.plane_limit, 0},
 #ifdef DG_SYM
-        {"sym", &S.use_sym, 0}, {"sym_min_k2", &S.sym_min_k2, 1}, {"sym_rc", &S.sym_rc, 1}, {"sym_dbg", &S.sym_dbg, 0},
+        {"sym", &S.use_sym, 0}, {"sym_min_k2", &S.sym_min_k2, 1}, {"sym_rc", &S.sym_rc, 1}, {"sym_dbg", &S.sym_dbg, 0}, {"sym_fold", &S.sym_fold, 0},
 #endif
         {"test_poison_level", &S.test_poison_level, 0}, {"test_poison_byte", &S.test_poison_byte, 0},
     };

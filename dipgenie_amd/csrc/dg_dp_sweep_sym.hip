@@ -170,22 +170,14 @@ __device__ __forceinline__ unsigned long long sym_digest(const LevelHead &H, con
     return sum;
 }
 
+// one (tile of SYM_ROWS rows, slot block, chunk): every wave one row
 template <int RC, bool DIGEST, bool GENERAL>
-__global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
-                                                                      int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
-                                                                      FastArgs A, LevelDesc d, int lvl, int n_heavy, const int32_t *__restrict__ heavy_rows, int dbg) {
-    __shared__ SymShared<RC> sh;
-    if (dbg & 16) return;
-    const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
-    publish_level(A.progress, lvl);
+__device__ __forceinline__ void sym_tile(const LevelHead &H, const FastArgs &A, const LevelDesc &d, SymShared<RC> &sh, __amdgpu_buffer_rsrc_t cur_rsrc, int32_t *__restrict__ nxt,
+                                         int tile, int g, int r0, int lvl, int n_heavy, bool clear_dead, int dbg) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const int g = (int)blockIdx.x, r0 = (int)blockIdx.y * RC, RP = H.RP, k2 = d.k2;
-    int32_t *__restrict__ nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
-    const __amdgpu_buffer_rsrc_t cur_rsrc = state_rsrc(cur, buf_bytes);
-    const bool heavy_region = (int)blockIdx.z < n_heavy;
-    const int tile = (int)blockIdx.z - n_heavy;
-    // vertices without in-edges: unreachable as row and as column; the tiles of block 0 clear both for their rows
-    if (!heavy_region && g == 0 && d.ndead > 0) {
+    const int RP = H.RP, k2 = d.k2;
+    // vertices without in-edges: unreachable as row and as column; the tile's first workgroup clears both for its rows
+    if (clear_dead && d.ndead > 0) {
         const int row0 = tile * SYM_ROWS, nrow = min(SYM_ROWS, k2 - row0);
         for (int t = (int)threadIdx.x; t < nrow * d.ndead * RC; t += SYM_ROWS * 64) {
             const int q = t % RC, rest = t / RC;
@@ -197,12 +189,11 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
             }
         }
     }
+    if (g < 0) return;                                                  // (a tile whose rows are all dead vertices behind the last block: clearing only)
     // first load round: the block's slot records (the same in every wave of the workgroup) and the wave's row record
-    const uint2 sl = slots_l[g * 64 + lane];
-    int i2;
-    if (heavy_region) { const int h = (int)blockIdx.z; i2 = h < HEAVY_INLINE ? (int)d.heavy_in[h] : heavy_rows[d.heavy_first + h]; }
-    else i2 = tile * SYM_ROWS + wave;
-    const uint4 rr = rowrec_l[min(i2, k2 - 1)];
+    const uint2 sl = H.slots_l[g * 64 + lane];
+    const int i2 = tile * SYM_ROWS + wave;
+    const uint4 rr = H.rowrec_l[min(i2, k2 - 1)];
     if (dbg & 32) { asm volatile("" ::"v"(sl.x), "v"(rr.x)); return; }
     int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
     const bool act0 = sl.x != 0xFFFFFFFFu;
@@ -212,9 +203,10 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
     int nblk = 1;
     if (GENERAL) {
         if (steps == 14) return;                                        // continuation block of a giant column: walked by the wave of its first block
-        if (steps == 15) { nblk = ((int)rowrec_l[__builtin_amdgcn_readfirstlane(j2)].y + 63) >> 6; steps = 6; }
+        if (steps == 15) { nblk = ((int)H.rowrec_l[__builtin_amdgcn_readfirstlane(j2)].y + 63) >> 6; steps = 6; }
     }
     const int cmax = __builtin_amdgcn_readlane(j2, 63 - __builtin_clzll(am));   // last column of the block (columns ascend with the lanes)
+    if (cmax < tile * SYM_ROWS) return;                                 // every row of the tile lies beyond the block's last column (workgroup-uniform)
     const int pj2 = lane_up1(j2);
     const bool head0 = act0 & ((lane == 0) | (pj2 != j2));
     int bval[RC];
@@ -222,47 +214,10 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
 #pragma unroll
     for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
     unsigned long long dsum = 0;
-    if (heavy_region) {
-        // ---- one fan-in row, its in-edges dealt to the SYM_ROWS waves ----
-        if (dbg & 1) return;
-        if (cmax < i2) return;                                          // the whole block lies below the diagonal (workgroup-uniform)
-        const int du = (int)rr.y;
-        uint32_t mypu = 0;
-        if (!GENERAL && rowx_stride > 0 && lane < rowx_stride) mypu = rowx_l[i2 * rowx_stride + lane];
-        sym_gather<RC, GENERAL>(H, A, cur_rsrc, rr, sl, mypu, g, nblk, i2, r0, (du * wave) / SYM_ROWS, (du * (wave + 1)) / SYM_ROWS, bval, bord);
-        if (wave > 0) {
-#pragma unroll
-            for (int q = 0; q < RC; ++q) sh.ex[wave - 1][q][lane] = make_uint2((uint32_t)bval[q], bord[q]);
-        }
-        __syncthreads();
-        if (wave > 0) return;
-        for (int p = 0; p < SYM_ROWS - 1; ++p) {
-#pragma unroll
-            for (int q = 0; q < RC; ++q) { const uint2 o = sh.ex[p][q][lane]; merge_best_sym((int)o.x, o.y, true, bval[q], bord[q]); }
-        }
-        sym_column_max<RC>(steps, j2, bval, bord);
-        if (head0 && j2 >= i2) {
-#pragma unroll
-            for (int q = 0; q < RC; ++q) {
-                const int r2 = r0 + q;
-                if (r2 < RP) {
-                    const int ia = (i2 * RP + r2) * k2 + j2, ib = (j2 * RP + r2) * k2 + i2;
-                    nxt[ia] = bval[q];
-                    if (A.bp) A.bp[d.bp_off + ia] = (uint16_t)~bord[q];
-                    if (j2 > i2) { nxt[ib] = bval[q]; if (A.bp) A.bp[d.bp_off + ib] = (uint16_t)(~bord[q] >> 16); }
-                    if (DIGEST && bval[q] != NEG_INF) dsum += sym_digest(H, A, rr, k2, i2, j2, r2, bval[q], bord[q]);
-                }
-            }
-        }
-        if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
-        return;
-    }
-    // ---- a tile of SYM_ROWS rows, one wave each ----
-    if (cmax < tile * SYM_ROWS) return;                                 // every row of the tile lies beyond the block's last column (workgroup-uniform)
     const bool row_on = (i2 < k2) & (i2 <= cmax) & !((n_heavy > 0) & ((int)rr.y > COOP_MIN));
     if (row_on) {
         uint32_t mypu = 0;
-        if (!GENERAL && rowx_stride > 0 && lane < rowx_stride) mypu = rowx_l[i2 * rowx_stride + lane];
+        if (!GENERAL && H.rowx_stride > 0 && lane < H.rowx_stride) mypu = H.rowx_l[i2 * H.rowx_stride + lane];
         if (!(dbg & 8)) sym_gather<RC, GENERAL>(H, A, cur_rsrc, rr, sl, mypu, g, nblk, i2, r0, 0, (int)rr.y, bval, bord);
         sym_column_max<RC>(steps, j2, bval, bord);
     }
@@ -305,6 +260,98 @@ __global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4
     }
 }
 
+// fold = 1 (lean levels with at most 64 blocks): the (tile, block) pairs above the diagonal are dealt to the grid without holes.  Tile t needs
+// the blocks g >= gmin(t), gmin(t) = number of blocks that end in front of column 16 t's first in-edge (one vector load of the level's block
+// boundaries, two ballots); workgroup (x, z) takes pair x of tile z, then of tile NT - 1 - z: together about NB + 1 pairs whatever z.
+template <int RC, bool DIGEST, bool GENERAL>
+__global__ __launch_bounds__(SYM_ROWS * 64) void dp_sweep_sym_kernel(const uint4 *rowrec_l, const uint2 *slots_l, const uint32_t *rowx_l, const int32_t *cur, const uint16_t *dm,
+                                                                      int rowx_stride, int nblocks, int rp_k, int pad_bytes, int dT, uint32_t buf_bytes,   // 16 dwords: preloaded
+                                                                      FastArgs A, LevelDesc d, int lvl, int n_heavy, const int32_t *__restrict__ heavy_rows, int dbg,
+                                                                      int fold, const uint32_t *__restrict__ gb_l) {
+    __shared__ SymShared<RC> sh;
+    if (dbg & 16) return;
+    const LevelHead H{rowrec_l, slots_l, rowx_l, cur, dm, rowx_stride, rp_k & 0x1FFF, rp_k >> 13, pad_bytes, dT, buf_bytes};
+    publish_level(A.progress, lvl);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const int r0 = (int)blockIdx.y * RC, RP = H.RP, k2 = d.k2;
+    int32_t *__restrict__ nxt = (int32_t *)(A.ring + (size_t)DG_SLOT(A, lvl) * A.slot_bytes + A.pad_bytes);
+    const __amdgpu_buffer_rsrc_t cur_rsrc = state_rsrc(cur, buf_bytes);
+    if ((int)blockIdx.z >= n_heavy) {
+        const int z = (int)blockIdx.z - n_heavy;
+        if (GENERAL || !fold) { sym_tile<RC, DIGEST, GENERAL>(H, A, d, sh, cur_rsrc, nxt, z, (int)blockIdx.x, r0, lvl, n_heavy, blockIdx.x == 0, dbg); return; }
+        const int NT = (k2 + SYM_ROWS - 1) / SYM_ROWS, t1 = z, t2 = NT - 1 - z;
+        const uint32_t e1 = rowrec_l[t1 * SYM_ROWS].x, e2 = rowrec_l[min(t2 * SYM_ROWS, k2 - 1)].x;
+        const uint32_t gend = lane < nblocks ? gb_l[lane + 1] : 0xFFFFFFFFu;       // first in-edge behind block `lane`
+        const int gmin1 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(gend <= e1)), gmin2 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(gend <= e2));
+        const int need1 = nblocks - gmin1, need2 = t2 > t1 ? nblocks - gmin2 : 0;
+        const int n1 = max(need1, 1), n2 = t2 > t1 ? max(need2, 1) : 0;            // (a tile without a block of its own still has its dead vertices cleared)
+        bool first = true;
+        for (int x = (int)blockIdx.x; x < n1 + n2; x += (int)gridDim.x) {            // (one trip, unless a pair of tiles needs more blocks than the grid is wide)
+            if (!first) __syncthreads();                                            // the tile in LDS is free again
+            first = false;
+            if (x < n1) sym_tile<RC, DIGEST, GENERAL>(H, A, d, sh, cur_rsrc, nxt, t1, x < need1 ? gmin1 + x : -1, r0, lvl, n_heavy, x == 0, dbg);
+            else sym_tile<RC, DIGEST, GENERAL>(H, A, d, sh, cur_rsrc, nxt, t2, x - n1 < need2 ? gmin2 + (x - n1) : -1, r0, lvl, n_heavy, x == n1, dbg);
+        }
+        return;
+    }
+    // ---- one fan-in row, its in-edges dealt to the SYM_ROWS waves ----
+    if (dbg & 1) return;
+    const int g = (int)blockIdx.x;
+    if (g >= nblocks) return;
+    const uint2 sl = slots_l[g * 64 + lane];
+    const int h = (int)blockIdx.z;
+    const int i2 = h < HEAVY_INLINE ? (int)d.heavy_in[h] : heavy_rows[d.heavy_first + h];
+    const uint4 rr = rowrec_l[i2];
+    int steps = __builtin_amdgcn_readfirstlane((int)(sl.y >> 28));
+    const bool act0 = sl.x != 0xFFFFFFFFu;
+    const int j2 = act0 ? (int)((sl.x >> 16) & 0x7FFFu) : -1 - lane;
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(act0);
+    if (am == 0) return;
+    int nblk = 1;
+    if (GENERAL) {
+        if (steps == 14) return;
+        if (steps == 15) { nblk = ((int)rowrec_l[__builtin_amdgcn_readfirstlane(j2)].y + 63) >> 6; steps = 6; }
+    }
+    const int cmax = __builtin_amdgcn_readlane(j2, 63 - __builtin_clzll(am));
+    if (cmax < i2) return;                                              // the whole block lies below the diagonal (workgroup-uniform)
+    const int pj2 = lane_up1(j2);
+    const bool head0 = act0 & ((lane == 0) | (pj2 != j2));
+    int bval[RC];
+    uint32_t bord[RC];
+#pragma unroll
+    for (int q = 0; q < RC; ++q) { bval[q] = NEG_INF; bord[q] = 0; }
+    unsigned long long dsum = 0;
+    const int du = (int)rr.y;
+    uint32_t mypu = 0;
+    if (!GENERAL && rowx_stride > 0 && lane < rowx_stride) mypu = rowx_l[i2 * rowx_stride + lane];
+    sym_gather<RC, GENERAL>(H, A, cur_rsrc, rr, sl, mypu, g, nblk, i2, r0, (du * wave) / SYM_ROWS, (du * (wave + 1)) / SYM_ROWS, bval, bord);
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) sh.ex[wave - 1][q][lane] = make_uint2((uint32_t)bval[q], bord[q]);
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int p = 0; p < SYM_ROWS - 1; ++p) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) { const uint2 o = sh.ex[p][q][lane]; merge_best_sym((int)o.x, o.y, true, bval[q], bord[q]); }
+    }
+    sym_column_max<RC>(steps, j2, bval, bord);
+    if (head0 && j2 >= i2) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+            const int r2 = r0 + q;
+            if (r2 < RP) {
+                const int ia = (i2 * RP + r2) * k2 + j2, ib = (j2 * RP + r2) * k2 + i2;
+                nxt[ia] = bval[q];
+                if (A.bp) A.bp[d.bp_off + ia] = (uint16_t)~bord[q];
+                if (j2 > i2) { nxt[ib] = bval[q]; if (A.bp) A.bp[d.bp_off + ib] = (uint16_t)(~bord[q] >> 16); }
+                if (DIGEST && bval[q] != NEG_INF) dsum += sym_digest(H, A, rr, k2, i2, j2, r2, bval[q], bord[q]);
+            }
+        }
+    }
+    if (DIGEST && dsum) atomicAdd(&A.digest[lvl], dsum);
+}
+
 // host side: launches the symmetric form for level l where it applies; false = the caller launches the plain form
 bool sweep_launch_sym(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
     LevelDesc &d = S.descs[l];
@@ -317,7 +364,11 @@ bool sweep_launch_sym(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         if (rc == 5) rc = 4; if (rc == 7) rc = 6;
         const int nh = S.use_coop ? d.n_heavy : 0;
         S.launch_hist[(40 + rc) * 4 + (d.fast_ok == 2 ? 2 : 0)]++;
-        const dim3 grid((unsigned)d.nblocks, (unsigned)((S.RP + rc - 1) / rc), (unsigned)((d.k2 + SYM_ROWS - 1) / SYM_ROWS + nh));
+        const int NT = (d.k2 + SYM_ROWS - 1) / SYM_ROWS;
+        const int fold = (S.sym_fold && d.fast_ok == 1 && d.nblocks <= 64 && d.ngroups == d.nblocks) ? 1 : 0;   // lean levels: groups are the blocks
+        // (fold: x = pair of a tile and its mirror tile, z = the lower half of the tiles; a fan-in row needs the first nblocks of the x range)
+        const dim3 grid((unsigned)(fold ? d.nblocks + 2 : d.nblocks), (unsigned)((S.RP + rc - 1) / rc), (unsigned)((fold ? (NT + 1) / 2 : NT) + nh));
+        const uint32_t *gb_l = X.A.grp_begin + d.grp_first;
         const FastArgs &F = X.F;
         const uint4 *rowrec_l = F.rowrec + d.b0;
         const uint2 *slots_l = F.slots + d.slot_first;
@@ -327,8 +378,8 @@ bool sweep_launch_sym(DpState &S, SweepLaunch &X, int l, hipStream_t s) {
         const uint16_t *dm = dT ? F.delta + d.delta_off - (int64_t)d.in_base * dT : F.delta_zero;
         const int rp_k = S.RP | (d.k << 13);
         const int32_t *hv = S.d_heavy.as<int32_t>();
-#define DG_SYM(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, true>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg); \
-                             else hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, false>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg); } while (0)
+#define DG_SYM(RCV, DG) do { if (d.fast_ok == 2) hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, true>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg, fold, gb_l); \
+                             else hipLaunchKernelGGL((dp_sweep_sym_kernel<RCV, DG, false>), grid, dim3(SYM_ROWS * 64), 0, s, rowrec_l, slots_l, rowx_l, cur, dm, d.rowx_stride, d.nblocks, rp_k, F.pad_bytes, dT, F.buf_bytes, F, d, l, nh, hv, (int)S.sym_dbg, fold, gb_l); } while (0)
 #define DG_SYM_RC(DG) do { switch (rc) { case 1: DG_SYM(1, DG); break; case 2: DG_SYM(2, DG); break; case 3: DG_SYM(3, DG); break; case 4: DG_SYM(4, DG); break; \
                                          case 6: DG_SYM(6, DG); break; default: DG_SYM(8, DG); break; } } while (0)
         if (S.want_digest) DG_SYM_RC(true); else DG_SYM_RC(false);

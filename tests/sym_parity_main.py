@@ -12,7 +12,8 @@ import oracle_py as orc
 from dipgenie_amd import capi
 
 MODES = {"rc4": {"sym_rc": 4}, "rc1": {"sym_rc": 1}, "rc2": {"sym_rc": 2}, "rc3": {"sym_rc": 3}, "rc6": {"sym_rc": 6}, "rc8": {"sym_rc": 8},
-         "rows_inline": {"coop": 0}, "plain_launches": {"graph_batch": 0}, "host_tables": {"host_tables": 1}, "no_rowx": {"rowx": 0}}
+         "rows_inline": {"coop": 0}, "plain_launches": {"graph_batch": 0}, "host_tables": {"host_tables": 1}, "no_rowx": {"rowx": 0},
+         "folded_grid": {"sym_fold": 1}, "folded_rc2": {"sym_fold": 1, "sym_rc": 2}, "folded_rc8_inline": {"sym_fold": 1, "sym_rc": 8, "coop": 0}}
 SHAPES = [dict(), dict(max_width=30, n_levels=40, R=6), dict(max_width=3, n_levels=200, R=2), dict(R=0), dict(p_w1=0.9, R=18),
           dict(p_colour=0.0), dict(p_colour=1.0, max_list=9, n_colours=10), dict(max_width=70, n_levels=10, R=4, extra_edges=3.0),
           dict(min_width=1, max_width=1, n_levels=30, R=3), dict(max_width=12, n_levels=300, R=5, p_colour=0.1),
@@ -20,7 +21,8 @@ SHAPES = [dict(), dict(max_width=30, n_levels=40, R=6), dict(max_width=3, n_leve
           dict(max_width=30, n_levels=60, R=18, p_w1=0.3, p_colour=0.5), dict(max_width=60, n_levels=30, R=32, p_w1=0.6),
           dict(max_width=64, n_levels=30, R=3, p_w1=0.5, p_colour=0.8), dict(max_width=3, n_levels=8, R=2, extra_edges=100.0),
           dict(min_width=20, max_width=24, n_levels=8, R=2, extra_edges=70.0), dict(min_width=15, max_width=18, n_levels=40, R=7, p_colour=0.6),
-          dict(min_width=63, max_width=66, n_levels=12, R=9, p_w1=0.4, p_colour=0.3), dict(min_width=120, max_width=200, n_levels=6, R=5, p_colour=0.3, extra_edges=0.5)]
+          dict(min_width=63, max_width=66, n_levels=12, R=9, p_w1=0.4, p_colour=0.3), dict(min_width=120, max_width=200, n_levels=6, R=5, p_colour=0.3, extra_edges=0.5),
+          dict(min_width=40, max_width=90, n_levels=10, R=4, p_colour=0.3, extra_edges=0.05), dict(min_width=100, max_width=140, n_levels=5, R=3, extra_edges=0.02)]
 
 
 def fan_in_graph(k):
@@ -70,6 +72,6 @@ for mode, opts in sorted(MODES.items()):
     for k in (90, 200):
         both(ctx, fan_in_graph(k), (mode, "fan-in", k))
         n += 1
-    for k, v in {"sym_rc": 4, "coop": 1, "graph_batch": -1, "host_tables": 0, "rowx": 1}.items():
+    for k, v in {"sym_rc": 4, "coop": 1, "graph_batch": -1, "host_tables": 0, "rowx": 1, "sym_fold": 0}.items():
         ctx.dp_set_option(k, v)
 print("symmetric form parity ok", n, "graph x mode cases")
