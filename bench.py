@@ -551,8 +551,9 @@ def main():
         else:
             config = {"workload": f"{n4} x {rl4}-bp reads (30x, seed 30) on the synthetic MHC-24 panel (BASELINE configs[3]), k={K} w={W}, "
                                   f"dictionary of {int(dict_t.numel())} haplotype minimizers", "reads": n4, "read_length": rl4,
-                      "parallelism": f"reads sharded over {world} ranks; {backend}: async all-reduce int32[{int(dict_t.numel())}] (hit vector) + all-gather of the "
-                                     f"{world}x{world} send counts + all-to-all of (hash, count) runs by hash range + one fused all-reduce (range sizes, histogram, ids)"}
+                      "parallelism": f"reads sharded over {world} ranks; {backend}: async all-reduce int32[{int(dict_t.numel())}] (hit vector) + one all-to-all of fixed-size "
+                                     f"[{world}, 1 + {sk.cap}, 2] blocks of (hash, count) runs by hash range (run length in the payload; the calibrating warm-up step exchanged exact runs "
+                                     "behind an all-gather of the send counts) + one fused all-reduce (range sizes, histogram, ids, overflow flag); no host read inside a step"}
             line = {
                 "metric": "sketch_reads_per_s", "value": n4 * steps / elapsed, "unit": "reads/s",
                 "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
