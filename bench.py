@@ -9,7 +9,11 @@ segment set (5 real + 19 seeded mosaics with private variants), diploid -p2 -R18
 one pass of the hot path over that input, every input already resident in HBM: (a) minimizer scoring of the read set
 (HIP sketch, dictionary join, ids, histogram), then (b) the pair-of-paths DP (delta precompute, level sweep, traceback).
 `value` = DP state cells / s.  The same line carries `sketch_config4`: the 30x read set (configs[3]) scored on this one
-rank -- the N = 1 point of the scaling curve below.
+rank -- the N = 1 point of the scaling curve below -- and, measured by child processes after this process has released its device
+memory: `hip_runtime.native_runtime_check` (the DP passes again from bin/dg_dp_bench, plain C++ over the C ABI on the HIP runtime the
+library was built against), `config4_one_run` (configs[3] as one job: the plain CLI, bin/DipGenie --gpus 1 over RCCL and
+python -m dipgenie_amd.run_sharded on the 30x reads as a FASTA), `config5` (configs[4] at a tenth of its size through the CLI: value-pass
+cells/s, recompute factor, s8d fraction and counter bytes) and `cpu_baseline` (the reference binary on a prefix panel).
 
 N > 1 (BASELINE.json configs[3]): what shards is the minimizer scoring -- north_star: "throughput ... reported at 1 GPU
 (DP) and 1/2/4/8 GPUs (minimizer scoring)"; the DP is a chain of 1.4 x 10^5 dependent levels and does not shard
