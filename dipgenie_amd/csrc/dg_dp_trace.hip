@@ -123,20 +123,20 @@ __global__ __launch_bounds__(64) void dp_trace_chain_spec_kernel(const LevelDesc
             }
             // unrolled by hand (8 steps per trip): the loop's back edge copies the registers of the loads in flight, and so
             // waits for them -- one un-overlapped step per trip
-#define DG_CHAIN_STOP(T) (W.value == CHAIN_CORRUPT || (T) >= n)
-#define DG_CHAIN_STEP(T, X, Y, DC, DN) DN = DG_DESC((T) + 1); chain_spec_step(W, base - (T), l_lo, RP, DC, DN, bp, rowrec, in_edge, hops, (T), lane, X, Y)
+#define DG_WALK_STOP(T) (W.value == CHAIN_CORRUPT || (T) >= n)
+#define DG_WALK_STEP(T, X, Y, DC, DN) DN = DG_DESC((T) + 1); chain_spec_step(W, base - (T), l_lo, RP, DC, DN, bp, rowrec, in_edge, hops, (T), lane, X, Y)
             for (int t = 0; t < n; t += 8) {
-                DG_CHAIN_STEP(t, A, B, D0, D1);     if (DG_CHAIN_STOP(t + 1)) break;
-                DG_CHAIN_STEP(t + 1, B, A, D1, D0); if (DG_CHAIN_STOP(t + 2)) break;
-                DG_CHAIN_STEP(t + 2, A, B, D0, D1); if (DG_CHAIN_STOP(t + 3)) break;
-                DG_CHAIN_STEP(t + 3, B, A, D1, D0); if (DG_CHAIN_STOP(t + 4)) break;
-                DG_CHAIN_STEP(t + 4, A, B, D0, D1); if (DG_CHAIN_STOP(t + 5)) break;
-                DG_CHAIN_STEP(t + 5, B, A, D1, D0); if (DG_CHAIN_STOP(t + 6)) break;
-                DG_CHAIN_STEP(t + 6, A, B, D0, D1); if (DG_CHAIN_STOP(t + 7)) break;
-                DG_CHAIN_STEP(t + 7, B, A, D1, D0); if (DG_CHAIN_STOP(t + 8)) break;
+                DG_WALK_STEP(t, A, B, D0, D1);     if (DG_WALK_STOP(t + 1)) break;
+                DG_WALK_STEP(t + 1, B, A, D1, D0); if (DG_WALK_STOP(t + 2)) break;
+                DG_WALK_STEP(t + 2, A, B, D0, D1); if (DG_WALK_STOP(t + 3)) break;
+                DG_WALK_STEP(t + 3, B, A, D1, D0); if (DG_WALK_STOP(t + 4)) break;
+                DG_WALK_STEP(t + 4, A, B, D0, D1); if (DG_WALK_STOP(t + 5)) break;
+                DG_WALK_STEP(t + 5, B, A, D1, D0); if (DG_WALK_STOP(t + 6)) break;
+                DG_WALK_STEP(t + 6, A, B, D0, D1); if (DG_WALK_STOP(t + 7)) break;
+                DG_WALK_STEP(t + 7, B, A, D1, D0); if (DG_WALK_STOP(t + 8)) break;
             }
-#undef DG_CHAIN_STOP
-#undef DG_CHAIN_STEP
+#undef DG_WALK_STOP
+#undef DG_WALK_STEP
 #undef DG_DESC
             if (lane < n && W.value != CHAIN_CORRUPT)               // the path holds in-edge style words: source | weight << 31
                 path[base - lane] = make_uint2((hops & 0x7FFFu) | (((hops >> 30) & 1u) << 31), ((hops >> 15) & 0x7FFFu) | ((hops >> 31) << 31));
