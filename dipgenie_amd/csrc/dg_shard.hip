@@ -144,8 +144,9 @@ struct ScoreJob {                                        // shared by the rank t
 #define DG_RHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { J.rc[r] = DG_ERR_HIP; J.err[r] = std::string(#call " failed: ") + hipGetErrorString(e_); return; } } while (0)
 #define DG_RNCCL(call) do { ncclResult_t e_ = (call); if (e_ != ncclSuccess) { J.rc[r] = DG_ERR_HIP; J.err[r] = std::string(#call " failed: ") + S.rccl.GetErrorString(e_); return; } } while (0)
 
-// One rank.  A rank that fails keeps walking through the barriers (the others must not wait for it forever) but issues no collective:
-// `alive` is re-evaluated by everybody behind every barrier.
+// One rank.  A rank that fails keeps walking through the barriers (the others must not wait for it forever), and nobody enters the
+// exchange unless every rank came through its local part (all_ok(), evaluated behind a barrier).  A failure INSIDE the grouped RCCL
+// exchange can still leave the peers waiting in it: that is RCCL's contract.
 void score_rank(ScoreJob &J, int r) {
     dg_shard &S = *J.S;
     const int W = S.W;
